@@ -1,0 +1,246 @@
+"""Headline benchmark: CG-iteration throughput of the 3D p=7 Laplacian.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one CG iteration (cg.py:75-86: operator apply + the fused vector
+kernels) on the Dirichlet Laplacian of BASELINE config 2: a 64^3 structured hex
+mesh on [0,1]^3 refined to GLL p=7 nodes (N = 449^3 = 90.5 M DOFs), fp64,
+synthetic right-hand side, everything resident in HBM before the timed region.
+For N > 1 every rank owns one 64^3 block of a (px,py,pz)-blocked mesh (weak
+scaling; 8 GPUs = the 128^3, 2 M element mesh) and the shared-DOF exchange runs
+over RCCL.
+
+Prints ONE JSON line (rank 0): metric GDOF/s per CG iteration (whole job), the
+roofline of the dominant kernel (fused gather-apply-scatter, HBM-bound) and the
+CPU baseline (oracle = reference algorithm restated, timed on the host cores on
+a bounded sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_apply(E, n, N, sizeof=8, ngeo=6):
+  """SURVEY 8(d) stored-factor model: idx 4 E n + u s N + geo 6 s E Q + out s N."""
+  return 4 * E * n + sizeof * N + ngeo * sizeof * E * n + sizeof * N
+
+
+def block_grid(world):
+  return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(
+      world, (world, 1, 1))
+
+
+def cpu_baseline(P, budget_s=20.0):
+  """Times the oracle (reference algorithm: dense Kronecker element matrices,
+  9+1 stored geometric arrays, un-fused CG) on this host: one CG iteration of
+  the same p=7 Dirichlet Laplacian on a bounded 6^3-element sample."""
+  import torch
+  from oracle import sfem_oracle as O
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.core.interpolation import Nodes1D, NodeType
+  from swirl_fem_amd.core.mesh_refiner import refine_premesh
+  ne = 6
+  rp = refine_premesh(unit_cube_mesh(ne, ndim=3),
+                      Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE))
+  fes = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'), (P, 'gll'))
+  mask = np.zeros(rp.num_nodes)
+  mask[np.unique(rp.physical_groups['boundary'])] = 1.0
+  interior = 1.0 - mask
+
+  def A(u):
+    return interior * fes.scatter(fes.stiffness_local(fes.gather(u)))
+
+  rng = np.random.default_rng(0)
+  b = interior * rng.standard_normal(rp.num_nodes)
+  # un-fused CG body (cg.py:75-86), fixed iteration count
+  x = np.zeros_like(b)
+  r = b - A(x)
+  p = r.copy()
+  gamma = np.vdot(r, r)
+  iters, t0 = 0, time.perf_counter()
+  A(p)                                            # warm-up of caches / BLAS
+  t0 = time.perf_counter()
+  while True:
+    Ap = A(p)
+    alpha = gamma / np.vdot(p, Ap)
+    x = x + alpha * p
+    r = r - alpha * Ap
+    g2 = np.vdot(r, r)
+    p = r + (g2 / gamma) * p
+    gamma = g2
+    iters += 1
+    el = time.perf_counter() - t0
+    if iters >= 3 and (el > budget_s or iters >= 20):
+      break
+  return {
+      'value': rp.num_nodes * iters / el / 1e9, 'unit': 'GDOF/s',
+      'cores': 1,   # np.einsum without `optimize` runs on one thread
+      'kind': 'port',
+      'sample': f'{ne}^3 hex elements p={P - 1} ({rp.num_nodes} DOFs), {iters} '
+                f'CG iterations of the dense-Kronecker NumPy oracle in '
+                f'{el:.1f} s (reference-algorithm restatement, not JAX)',
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--warmup', type=int, default=10)
+  ap.add_argument('--n', type=int, default=64, help='elements per dim per GPU')
+  ap.add_argument('--p', type=int, default=7, help='polynomial order')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  from swirl_fem_amd.core.fespace import FiniteElementSpace
+  from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
+  from swirl_fem_amd.linalg.cg import CGRunner
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('launch N>1 with torch.distributed.run (see docstring)')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=device)
+
+  P = args.p + 1
+  grid = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
+  t_setup = time.perf_counter()
+  from swirl_fem_amd.distributed import blocks
+  part = blocks.build_block_partition(args.n, P, block_grid(world), rank,
+                                      device=device)
+  mesh = part.mesh
+  fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
+  op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'))
+  setup_s = time.perf_counter() - t_setup
+
+  N_local = mesh.num_nodes
+  E, n = mesh.elements.shape
+  N_global = part.num_global_nodes
+
+  g = torch.Generator(device=device).manual_seed(1234 + rank)
+  b = torch.randn(N_local, dtype=torch.float64, device=device, generator=g)
+  if 'boundary' in mesh.physical_masks:
+    b = b * (~mesh.physical_masks['boundary']).to(b.dtype)
+  # Partitioned CG follows the reference's solver convention
+  # (navier_stokes.py:436-438): A returns the *unassembled* local
+  # result, the preconditioner slot carries QQ^T (M = exchange), so plain local
+  # dots + one all-reduce are the global inner products.
+  out_buf = torch.empty_like(b)
+
+  def A(u):
+    return op.apply(u, 0.0, 1.0, out=torch.empty_like(u))
+
+  if world > 1:
+    run = CGRunner(A, b, tol=0.0, atol=0.0, maxiter=10 ** 9, M=mesh.exchange,
+                   reduce_fn=part.reduce_sum_)
+  else:
+    run = CGRunner(A, b, tol=0.0, atol=0.0, maxiter=10 ** 9)
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    run.step()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    run.step()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+  ms_per_step = 1e3 * elapsed / args.steps
+  value = N_global / (elapsed / args.steps) / 1e9
+
+  # ---- roofline of the dominant kernel: HIP events around the kernel only
+  u = run.p
+  lo, hi = op.zero_range
+  ev = [(torch.cuda.Event(enable_timing=True),
+         torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+  from swirl_fem_amd import _ops
+  for _ in range(3):
+    op.apply(u, 0.0, 1.0, out=out_buf)
+  torch.cuda.synchronize()
+  for s0, s1 in ev:
+    if hi > lo:
+      out_buf[lo:hi].zero_()                 # outside the event pair
+    s0.record()
+    _ops.helmholtz_apply(u, out_buf, op.enc, op.geo, op.dmat, 3, P, 0.0, 1.0,
+                         (0, 0))
+    s1.record()
+  torch.cuda.synchronize()
+  kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
+  # apply incl. the zero-fill of the shared range, as the solver issues it
+  s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
+      enable_timing=True)
+  s0.record()
+  for _ in range(args.steps):
+    op.apply(u, 0.0, 1.0, out=out_buf)
+  s1.record()
+  torch.cuda.synchronize()
+  apply_ms = s0.elapsed_time(s1) / args.steps
+  alg_bytes = algorithmic_bytes_per_apply(E, n, N_local)
+  achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+  if rank == 0:
+    res = {
+        'metric': 'GDOF/s per CG iteration, 3D p=%d Laplacian' % args.p,
+        'value': value, 'unit': 'GDOF/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {
+            'workload': '3D Laplacian CG iteration, %d^3 hex elements per GPU, '
+                        'p=%d GLL collocated, fp64, Dirichlet' % (args.n,
+                                                                  args.p),
+            'elements_per_gpu': E, 'dofs_global': N_global,
+            'blocks': 'x'.join(map(str, block_grid(world))),
+            'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
+            'apply_ms': apply_ms, 'setup_s': setup_s,
+        },
+        'roofline': {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'kernel': 'sfem::helmholtz_kernel<double, 8, 3, true, true>',
+            'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg_bytes,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      res['cpu_baseline'] = cpu_baseline(P)
+    else:
+      res['cpu_baseline'] = None
+    print(json.dumps(res))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,237 @@
+/*
+ * sfem.h -- C-ABI of libsfem_hip.so: MI355X (gfx950) kernels for the
+ * spectral-element operator-apply + gather-scatter hot path of swirl_fem.
+ *
+ * The reference (google-research/swirl-fem) is pure Python/JAX and has no FFI
+ * layer; its boundary for this path is the Python object API.  Each entry point
+ * below names the reference call site(s) it replaces (paths relative to the
+ * reference root).  swirl_fem_amd/_ops.py binds them with ctypes; a maintainer
+ * of the reference would bind them the same way.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller unless marked host;
+ *     nothing is allocated or freed inside a call, no call synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     legacy default stream);
+ *   - `dtype` is SFEM_F32 or SFEM_F64 and applies to every `void*` real array
+ *     of the call; index arrays are int32 with -1 (SFEM_SENTINEL) = "missing";
+ *   - element-local arrays are (E, n) with n = P^ndim and lexicographic node
+ *     order inside an element, axis 0 slowest (reference core/mesh.py:39-46);
+ *     quadrature arrays are (E, Q), Q = q^ndim, same ordering;
+ *   - vector fields carry their `ncomp` components innermost: (N, ncomp),
+ *     (E, n, ncomp), (E, Q, ncomp), gradients (E, Q, ndim, ncomp) with
+ *     [j][k] = d u_k / d x_j (reference core/fespace.py:221-225);
+ *   - return value: SFEM_OK (0) or a negative error; sfem_last_error() gives a
+ *     thread-local message.  Nothing throws across the ABI.
+ */
+#ifndef SFEM_H_
+#define SFEM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFEM_ABI_VERSION 1
+
+enum { SFEM_F32 = 0, SFEM_F64 = 1 };
+enum {
+  SFEM_OK = 0,
+  SFEM_EINVAL = -1,       /* bad argument (null pointer, size, dtype, ...)   */
+  SFEM_EHIP = -2,         /* a HIP runtime call failed                        */
+  SFEM_EUNSUPPORTED = -3  /* shape outside the compiled template range        */
+};
+#define SFEM_SENTINEL (-1)
+#define SFEM_MAX_P 16     /* nodes / quadrature points per direction          */
+
+/* Encoded element index used by the fused operators (sfem_encode_elements):
+ * low 30 bits node id (all ones = padding slot: reads 0, writes nothing),
+ * two flag bits on top.                                                      */
+#define SFEM_IDX_MASK 0x3FFFFFFF
+#define SFEM_IDX_PAD 0x3FFFFFFF
+#define SFEM_IDX_DIRICHLET 0x80000000u /* row zeroed by the interior mask     */
+#define SFEM_IDX_SHARED 0x40000000u /* node belongs to >1 slot: atomic add   */
+
+typedef void* sfem_stream_t;
+
+int sfem_abi_version(void);
+const char* sfem_last_error(void);
+
+/* ---------------------------------------------------------------- gather ---
+ * out[i] = indices[i] == -1 ? fill : u[indices[i]]          i in [0, count)
+ * Replaces gather_scatter.gather (core/gather_scatter.py:121-127) /
+ * Mesh.gather (core/mesh.py:155-160).                                        */
+int sfem_gather(const void* u, const int32_t* indices, void* out,
+                int64_t count, double fill, int dtype, sfem_stream_t stream);
+
+/* out[i, k] = indices[i] == -1 ? 0 : x[indices[i], k]   k in [0, ncomp)
+ * Replaces the vmapped gathers Mesh.element_coords (core/mesh.py:170-172) and
+ * StokesVelocity.gather (navier_stokes/navier_stokes.py:210-211).            */
+int sfem_gather_rows(const void* x, const int32_t* indices, void* out,
+                     int64_t count, int ncomp, int dtype, sfem_stream_t stream);
+
+/* --------------------------------------------------------------- scatter ---
+ * out[indices[i], k] += u_local[i, k]; entries with index -1 are skipped.
+ * `out` (num_nodes, ncomp) is zero-filled by the call first.  Accumulation
+ * uses HBM float atomics (order not reproducible).
+ * Replaces gather_scatter.scatter (core/gather_scatter.py:130-133) /
+ * Mesh.scatter (core/mesh.py:165-168).                                       */
+int sfem_scatter_add(const void* u_local, const int32_t* indices, void* out,
+                     int64_t count, int64_t num_nodes, int ncomp, int dtype,
+                     sfem_stream_t stream);
+
+/* Deterministic direct-stiffness sum through the inverse map (CSR by node):
+ * out[v, k] = sum_{s in [offsets[v], offsets[v+1])} u_local[slots[s], k],
+ * summed in slot order, so results are bitwise reproducible.                 */
+int sfem_scatter_csr(const void* u_local, const int64_t* offsets,
+                     const int32_t* slots, void* out, int64_t num_nodes,
+                     int ncomp, int dtype, sfem_stream_t stream);
+
+/* -------------------------------------------------------------- exchange ---
+ * Unpartitioned QQ^T (periodic images), core/gather_scatter.py:189-261 with
+ * axis_name=None:  out = u;  sums[unique[i]] += u[gidx[i]];
+ * out[gidx[i]] = sums[unique[i]].   `sums` is caller workspace of num_unique
+ * reals (zeroed by the call).  gidx entries of -1 are skipped.               */
+int sfem_exchange_local(const void* u, void* out, const int32_t* gidx,
+                        const int32_t* unique, int64_t count,
+                        int64_t num_nodes, void* sums, int64_t num_unique,
+                        int ncomp, int dtype, sfem_stream_t stream);
+
+/* Partitioned QQ^T, the pack / unpack halves around the RCCL neighbour
+ * exchange that replaces lax.psum (core/gather_scatter.py:247-248):
+ *   pack:       buf[i, k] = idx[i] == -1 ? 0 : u[idx[i], k]
+ *   unpack_add: u[idx[i], k] += buf[i, k]  (idx unique within one call)      */
+int sfem_pack(const void* u, const int32_t* idx, void* buf, int64_t count,
+              int ncomp, int dtype, sfem_stream_t stream);
+int sfem_unpack_add(const void* buf, const int32_t* idx, void* u,
+                    int64_t count, int ncomp, int dtype, sfem_stream_t stream);
+
+/* ------------------------------------------------------ geometric factors ---
+ * From element node coordinates (E, n, ndim) computes, per quadrature point,
+ *   jac[i][j]  = d x_j / d xi_i      (core/fespace.py:338, via I1/G1 factors)
+ *   invjac     = jac^-1  (E, Q, ndim, ndim)   (core/fespace.py:345)
+ *   jacdet     = det jac (E, Q), signed       (core/fespace.py:346)
+ *   quad_coords (E, Q, ndim) or NULL          (core/fespace.py:332-333)
+ * interp1 (q, P) = 1D interpolation matrix, grad1 (q, P) = interp1 @ D1, both
+ * row-major device arrays of `dtype`.                                        */
+int sfem_geom_factors(const void* elem_coords, const void* interp1,
+                      const void* grad1, int64_t num_elements, int ndim, int P,
+                      int q, void* invjac, void* jacdet, void* quad_coords,
+                      int dtype, sfem_stream_t stream);
+
+/* ------------------------------------------------------- basis evaluation ---
+ * Sum-factorised evaluation of nodal fields at quadrature points
+ * (core/interpolation.py:254-263, :288-292 vmapped by core/fespace.py:178-225):
+ *   val  (E, Q, ncomp)        = (I x .. x I) u                  or NULL
+ *   grad (E, Q, ndim, ncomp)  = invjac . reference gradient     or NULL
+ * invjac == NULL returns the reference-space gradient.  `collocated` != 0
+ * skips the interpolation for `val` exactly like interpolation.py:257-258.   */
+int sfem_basis_eval(const void* u_local, const void* interp1,
+                    const void* grad1, const void* invjac, void* val,
+                    void* grad, int64_t num_elements, int ndim, int P, int q,
+                    int ncomp, int collocated, int dtype, sfem_stream_t stream);
+
+/* Exact transpose of sfem_basis_eval composed with quadrature: the operator
+ * action produced by jax.linear_transpose in FiniteElementSpace.local_covector
+ * (core/fespace.py:458-471):
+ *   out[e, n, k] = sum_q wdet[e,q] ( val-basis^T c0 + grad-basis^T invjac^T c1 )
+ * c0 (E, Q, ncomp) or NULL; c1 (E, Q, ndim, ncomp) or NULL; wdet (E, Q) =
+ * jacdet * quadrature weight.                                                */
+int sfem_basis_eval_t(const void* c0, const void* c1, const void* interp1,
+                      const void* grad1, const void* invjac, const void* wdet,
+                      void* out, int64_t num_elements, int ndim, int P, int q,
+                      int ncomp, int collocated, int dtype,
+                      sfem_stream_t stream);
+
+/* --------------------------------------------------- fused Helmholtz apply ---
+ * Collocated (quadrature points == GLL nodes) operator
+ *     out = mask * scatter( lambda0 * B_local(g) + lambda1 * A_local(g) ),
+ *     g = gather(u)
+ * i.e. the mass form u.v, the stiffness form grad u : grad v and their
+ * combination H = (beta_k/dt) B + mu A in one pass over the elements:
+ * examples/poisson.py:141-154, navier_stokes.py:220-236, :295-307, :431.
+ * Setup builds, per quadrature point, the symmetric factors
+ *     geo[0..ng) = w detJ (J^-1 J^-T)  (ng = 3 in 2D, 6 in 3D: 00,01,(02),11,(12),(22))
+ *     geo[ng]    = w detJ
+ * laid out (E, ng+1, Q) (sfem_helmholtz_setup), and the encoded indices
+ * (sfem_encode_elements).                                                    */
+int sfem_helmholtz_setup(const void* invjac, const void* jacdet,
+                         const void* weights_nd /* (Q,) */, void* geo,
+                         int64_t num_elements, int ndim, int Q, int dtype,
+                         sfem_stream_t stream);
+
+/* enc[i] = node id | flags.  dirichlet (num_nodes,) uint8 or NULL,
+ * multiplicity (num_nodes,) int32 = number of slots referencing each node.   */
+int sfem_encode_elements(const int32_t* elements, const uint8_t* dirichlet,
+                         const int32_t* multiplicity, int32_t* enc,
+                         int64_t count, sfem_stream_t stream);
+
+typedef struct sfem_helmholtz_args {
+  const void* u;          /* (N, ncomp)                                       */
+  void* out;              /* (N, ncomp); every entry is written by the call   */
+  const int32_t* enc;     /* (E, n) encoded indices                           */
+  const void* geo;        /* (E, ng+1, Q)                                     */
+  const void* dmat;       /* HOST pointer: (P, P) 1D differentiation matrix,  */
+                          /*   row-major, of `dtype`                          */
+  int64_t num_elements;
+  int64_t num_nodes;
+  int64_t zero_begin;     /* out[zero_begin:zero_end) is cleared first: must  */
+  int64_t zero_end;       /*   cover every SHARED node and every unreferenced */
+  int32_t ndim;           /*   node                                           */
+  int32_t P;
+  int32_t ncomp;
+  int32_t dtype;
+  double lambda0;         /* mass coefficient                                 */
+  double lambda1;         /* stiffness coefficient                            */
+} sfem_helmholtz_args;
+
+int sfem_helmholtz_apply(const sfem_helmholtz_args* args, sfem_stream_t stream);
+
+/* Element-local variant (no gather/scatter): out_local (E, n, ncomp).
+ * StokesVelocity.A_local / B_local (navier_stokes.py:220-236).
+ * `dmat` is a HOST pointer as in sfem_helmholtz_args.                        */
+int sfem_helmholtz_local(const void* u_local, void* out_local, const void* geo,
+                         const void* dmat, int64_t num_elements, int ndim,
+                         int P, int ncomp, double lambda0, double lambda1,
+                         int dtype, sfem_stream_t stream);
+
+/* ------------------------------------------------------------ CG kernels ---
+ * Preconditioned CG of linalg/cg.py:30-97 with device-resident scalars: no
+ * host synchronisation inside an iteration (the reference keeps its loop on
+ * device with lax.while_loop, cg.py:94-95).  `scalars` is a device array of
+ * SFEM_CG_NSCALARS doubles:
+ *   [0] gamma = r.M r   [1] p.Ap   [2] gamma_new   [3] alpha   [4] beta
+ *   [5] b.b   [6] atol2 = max(tol^2 b.b, atol^2)   [7] done (0/1)
+ *   [8] iterations
+ * Once `done` is set every kernel below is a no-op, so the host may run ahead
+ * and poll [7] asynchronously; the iterate and the iteration count are exactly
+ * those of a loop that tests the condition of cg.py:68-73 every iteration.
+ *
+ * sfem_dot:            *result  = sum a*b          (clears result first)
+ * sfem_dot_accumulate: *result += sum a*b
+ * sfem_cg_scalars:     phase 2 = init (after b.b and gamma0 are in place),
+ *                      phase 0 = after p.Ap, phase 1 = end of iteration
+ * sfem_cg_update_xr:   x += alpha p; r -= alpha Ap;  (cg.py:80-81)
+ *                      fuse_rr != 0 also accumulates gamma_new += r.r (M = I)
+ * sfem_cg_update_p:    p = z + beta p                (cg.py:84-85)          */
+#define SFEM_CG_NSCALARS 16
+int sfem_dot(const void* a, const void* b, int64_t count, double* result,
+             int dtype, sfem_stream_t stream);
+int sfem_dot_accumulate(const void* a, const void* b, int64_t count,
+                        double* result, int dtype, sfem_stream_t stream);
+int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
+                    double atol, sfem_stream_t stream);
+int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,
+                      int64_t count, double* scalars, int fuse_rr, int dtype,
+                      sfem_stream_t stream);
+int sfem_cg_update_p(void* p, const void* z, int64_t count, double* scalars,
+                     int dtype, sfem_stream_t stream);
+/* y = a*x + b*y (plain fused vector update used outside the CG core)         */
+int sfem_axpby(double a, const void* x, double b, void* y, int64_t count,
+               int dtype, sfem_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SFEM_H_ */

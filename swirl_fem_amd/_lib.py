@@ -1,0 +1,104 @@
+"""ctypes loader for the C-ABI library `libsfem_hip.so` (include/sfem.h).
+
+There is no CPU fallback: if the library is missing or a tensor is not on the
+GPU the call raises.  Build the library with `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C swirl_fem_amd/csrc -j8`.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsfem_hip.so')
+ABI_VERSION = 1
+
+SFEM_F32, SFEM_F64 = 0, 1
+SFEM_CG_NSCALARS = 16
+
+c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,
+                              ctypes.c_void_p)
+
+
+class HelmholtzArgs(ctypes.Structure):
+  """Mirror of `struct sfem_helmholtz_args`."""
+  _fields_ = [
+      ('u', c_ptr), ('out', c_ptr), ('enc', c_ptr), ('geo', c_ptr),
+      ('dmat', c_ptr), ('num_elements', c_i64), ('num_nodes', c_i64),
+      ('zero_begin', c_i64), ('zero_end', c_i64), ('ndim', c_i32),
+      ('P', c_i32), ('ncomp', c_i32), ('dtype', c_i32), ('lambda0', c_dbl),
+      ('lambda1', c_dbl),
+  ]
+
+
+# name -> argument types (all functions return int unless noted)
+SIGNATURES = {
+    'sfem_gather': [c_ptr, c_ptr, c_ptr, c_i64, c_dbl, c_i32, c_ptr],
+    'sfem_gather_rows': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    'sfem_scatter_add': [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32,
+                         c_ptr],
+    'sfem_scatter_csr': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                         c_ptr],
+    'sfem_exchange_local': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr,
+                            c_i64, c_i32, c_i32, c_ptr],
+    'sfem_pack': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    'sfem_unpack_add': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    'sfem_geom_factors': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32,
+                          c_ptr, c_ptr, c_ptr, c_i32, c_ptr],
+    'sfem_basis_eval': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
+                        c_i32, c_i32, c_i32, c_i32, c_i32, c_ptr],
+    'sfem_basis_eval_t': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                          c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                          c_ptr],
+    'sfem_helmholtz_setup': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                             c_i32, c_ptr],
+    'sfem_encode_elements': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
+    'sfem_helmholtz_apply': [ctypes.POINTER(HelmholtzArgs), c_ptr],
+    'sfem_helmholtz_local': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                             c_i32, c_dbl, c_dbl, c_i32, c_ptr],
+    'sfem_dot': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+    'sfem_dot_accumulate': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+    'sfem_cg_scalars': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr],
+    'sfem_cg_update_xr': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32,
+                          c_i32, c_ptr],
+    'sfem_cg_update_p': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+    'sfem_axpby': [c_dbl, c_ptr, c_dbl, c_ptr, c_i64, c_i32, c_ptr],
+    'sfem_abi_version': [],
+}
+
+_lib = None
+
+
+class SfemError(RuntimeError):
+  """A C-ABI call returned a non-zero status."""
+
+
+def load() -> ctypes.CDLL:
+  """Loads (once) and returns the library; raises if it is not built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise SfemError(
+        f'{LIB_PATH} is missing: the HIP extension has not been built. '
+        'Run `make -C swirl_fem_amd/csrc -j8` (needs hipcc, gfx950). There is '
+        'no CPU fallback.')
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, argtypes in SIGNATURES.items():
+    fn = getattr(lib, name)           # AttributeError if a symbol is missing
+    fn.argtypes = argtypes
+    fn.restype = ctypes.c_int
+  lib.sfem_last_error.argtypes = []
+  lib.sfem_last_error.restype = ctypes.c_char_p
+  if lib.sfem_abi_version() != ABI_VERSION:
+    raise SfemError(f'ABI version mismatch: library '
+                    f'{lib.sfem_abi_version()} != binding {ABI_VERSION}')
+  _lib = lib
+  return lib
+
+
+def check(status: int, who: str):
+  if status != 0:
+    msg = load().sfem_last_error().decode(errors='replace')
+    raise SfemError(f'{who} failed with status {status}: {msg}')

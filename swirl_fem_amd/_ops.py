@@ -1,0 +1,322 @@
+"""Tensor-level wrappers over the C-ABI (`include/sfem.h`).
+
+PyTorch is plumbing here: it owns the HBM allocations and the HIP stream; every
+number is produced by `libsfem_hip.so`.  All tensors must live on the GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from swirl_fem_amd import _lib
+
+_DT = {torch.float32: _lib.SFEM_F32, torch.float64: _lib.SFEM_F64}
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+  try:
+    return _DT[t.dtype]
+  except KeyError:
+    raise TypeError(f'unsupported dtype {t.dtype}; use float32 or float64')
+
+
+def _dev(*tensors):
+  """Checks that all tensors are contiguous GPU tensors on one device."""
+  dev = None
+  for t in tensors:
+    if t is None:
+      continue
+    if not t.is_cuda:
+      raise RuntimeError(
+          'swirl_fem_amd kernels run on MI355X device tensors only; got a '
+          f'{t.device} tensor (there is no CPU fallback)')
+    if not t.is_contiguous():
+      raise ValueError('expected a contiguous tensor')
+    if dev is None:
+      dev = t.device
+    elif t.device != dev:
+      raise ValueError(f'tensors on different devices: {dev} vs {t.device}')
+  return dev
+
+
+def _ptr(t):
+  return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+  return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _idx(indices: torch.Tensor) -> torch.Tensor:
+  if indices.dtype != torch.int32:
+    indices = indices.to(torch.int32)
+  return indices.contiguous()
+
+
+# ---------------------------------------------------------------- gather etc
+def gather(u, indices, fill):
+  indices = _idx(indices)
+  u = u.contiguous()
+  dev = _dev(u, indices)
+  out = torch.empty(indices.shape, dtype=u.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_gather(
+        _ptr(u), _ptr(indices), _ptr(out), indices.numel(), float(fill),
+        _dtype_code(u), _stream(dev)), 'sfem_gather')
+  return out
+
+
+def gather_rows(x, indices):
+  """x (N, nc), indices (...) -> (..., nc); SENTINEL rows are zero."""
+  indices = _idx(indices)
+  x = x.contiguous()
+  dev = _dev(x, indices)
+  nc = x.shape[-1]
+  out = torch.empty(tuple(indices.shape) + (nc,), dtype=x.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_gather_rows(
+        _ptr(x), _ptr(indices), _ptr(out), indices.numel(), nc,
+        _dtype_code(x), _stream(dev)), 'sfem_gather_rows')
+  return out
+
+
+def scatter_add(u_local, indices, num_nodes, ncomp=1):
+  indices = _idx(indices)
+  u_local = u_local.contiguous()
+  dev = _dev(u_local, indices)
+  shape = (num_nodes,) if ncomp == 1 and u_local.dim() == indices.dim() else (
+      num_nodes, ncomp)
+  out = torch.empty(shape, dtype=u_local.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_scatter_add(
+        _ptr(u_local), _ptr(indices), _ptr(out), indices.numel(), num_nodes,
+        ncomp, _dtype_code(u_local), _stream(dev)), 'sfem_scatter_add')
+  return out
+
+
+def scatter_csr(u_local, offsets, slots, num_nodes, ncomp=1):
+  u_local = u_local.contiguous()
+  dev = _dev(u_local, offsets, slots)
+  shape = (num_nodes,) if ncomp == 1 else (num_nodes, ncomp)
+  out = torch.empty(shape, dtype=u_local.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_scatter_csr(
+        _ptr(u_local), _ptr(offsets), _ptr(slots), _ptr(out), num_nodes, ncomp,
+        _dtype_code(u_local), _stream(dev)), 'sfem_scatter_csr')
+  return out
+
+
+_unique_cache = {}
+
+
+def exchange_local(u, gather_indices, unique_indices):
+  """Unpartitioned QQ^T; `unique_indices` is a host array (static)."""
+  u = u.contiguous()
+  gidx = _idx(gather_indices)
+  dev = _dev(u, gidx)
+  key = (id(unique_indices), str(dev))
+  cached = _unique_cache.get(key)
+  if cached is None or cached[0] is not unique_indices:
+    uni = torch.as_tensor(np.ascontiguousarray(unique_indices),
+                          dtype=torch.int32, device=dev)
+    num_unique = int(unique_indices.max()) + 1 if len(unique_indices) else 0
+    _unique_cache[key] = cached = (unique_indices, uni, num_unique)
+  _, uni, num_unique = cached
+  ncomp = 1 if u.dim() == 1 else u.shape[-1]
+  out = torch.empty_like(u)
+  sums = torch.empty((max(num_unique, 1), ncomp), dtype=u.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_exchange_local(
+        _ptr(u), _ptr(out), _ptr(gidx), _ptr(uni), gidx.numel(), u.shape[0],
+        _ptr(sums), num_unique, ncomp, _dtype_code(u), _stream(dev)),
+        'sfem_exchange_local')
+  return out
+
+
+def pack(u, idx):
+  ncomp = 1 if u.dim() == 1 else u.shape[-1]
+  u = u.contiguous()
+  dev = _dev(u, idx)
+  shape = (idx.numel(),) if u.dim() == 1 else (idx.numel(), ncomp)
+  buf = torch.empty(shape, dtype=u.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_pack(
+        _ptr(u), _ptr(idx), _ptr(buf), idx.numel(), ncomp, _dtype_code(u),
+        _stream(dev)), 'sfem_pack')
+  return buf
+
+
+def unpack_add(buf, idx, u):
+  """In place: u[idx] += buf."""
+  ncomp = 1 if u.dim() == 1 else u.shape[-1]
+  dev = _dev(buf, idx, u)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_unpack_add(
+        _ptr(buf), _ptr(idx), _ptr(u), idx.numel(), ncomp, _dtype_code(u),
+        _stream(dev)), 'sfem_unpack_add')
+  return u
+
+
+# ------------------------------------------------------------------ geometry
+def geom_factors(elem_coords, interp1, grad1, ndim, P, q, want_quad_coords):
+  elem_coords = elem_coords.contiguous()
+  dev = _dev(elem_coords, interp1, grad1)
+  E = elem_coords.shape[0]
+  Q = q ** ndim
+  dt = elem_coords.dtype
+  invjac = torch.empty((E, Q, ndim, ndim), dtype=dt, device=dev)
+  jacdet = torch.empty((E, Q), dtype=dt, device=dev)
+  quad = (torch.empty((E, Q, ndim), dtype=dt, device=dev)
+          if want_quad_coords else None)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_geom_factors(
+        _ptr(elem_coords), _ptr(interp1), _ptr(grad1), E, ndim, P, q,
+        _ptr(invjac), _ptr(jacdet), _ptr(quad), _dtype_code(elem_coords),
+        _stream(dev)), 'sfem_geom_factors')
+  return invjac, jacdet, quad
+
+
+def basis_eval(u_local, interp1, grad1, invjac, ndim, P, q, collocated,
+               want_val, want_grad):
+  """u_local (E, n, nc) -> val (E, Q, nc), grad (E, Q, d, nc)."""
+  u_local = u_local.contiguous()
+  dev = _dev(u_local, interp1, grad1, invjac)
+  E, _, nc = u_local.shape
+  Q = q ** ndim
+  dt = u_local.dtype
+  val = torch.empty((E, Q, nc), dtype=dt, device=dev) if want_val else None
+  grad = (torch.empty((E, Q, ndim, nc), dtype=dt, device=dev)
+          if want_grad else None)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_basis_eval(
+        _ptr(u_local), _ptr(interp1), _ptr(grad1), _ptr(invjac), _ptr(val),
+        _ptr(grad), E, ndim, P, q, nc, int(collocated), _dtype_code(u_local),
+        _stream(dev)), 'sfem_basis_eval')
+  return val, grad
+
+
+def basis_eval_t(c0, c1, interp1, grad1, invjac, wdet, ndim, P, q, nc,
+                 collocated):
+  """Transpose of `basis_eval` with quadrature: -> (E, n, nc)."""
+  c0 = None if c0 is None else c0.contiguous()
+  c1 = None if c1 is None else c1.contiguous()
+  dev = _dev(c0, c1, interp1, grad1, invjac, wdet)
+  E = wdet.shape[0]
+  out = torch.empty((E, P ** ndim, nc), dtype=wdet.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_basis_eval_t(
+        _ptr(c0), _ptr(c1), _ptr(interp1), _ptr(grad1), _ptr(invjac),
+        _ptr(wdet), _ptr(out), E, ndim, P, q, nc, int(collocated),
+        _dtype_code(wdet), _stream(dev)), 'sfem_basis_eval_t')
+  return out
+
+
+# ----------------------------------------------------------------- helmholtz
+def helmholtz_setup(invjac, jacdet, weights_nd):
+  dev = _dev(invjac, jacdet, weights_nd)
+  E, Q, ndim, _ = invjac.shape
+  ng = ndim * (ndim + 1) // 2
+  geo = torch.empty((E, ng + 1, Q), dtype=invjac.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_helmholtz_setup(
+        _ptr(invjac), _ptr(jacdet), _ptr(weights_nd), _ptr(geo), E, ndim, Q,
+        _dtype_code(invjac), _stream(dev)), 'sfem_helmholtz_setup')
+  return geo
+
+
+def encode_elements(elements, dirichlet_u8, multiplicity):
+  elements = _idx(elements)
+  dev = _dev(elements, dirichlet_u8, multiplicity)
+  enc = torch.empty_like(elements)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_encode_elements(
+        _ptr(elements), _ptr(dirichlet_u8), _ptr(multiplicity), _ptr(enc),
+        elements.numel(), _stream(dev)), 'sfem_encode_elements')
+  return enc
+
+
+def helmholtz_apply(u, out, enc, geo, dmat_host: np.ndarray, ndim, P,
+                    lambda0, lambda1, zero_range):
+  """out <- mask * scatter((l0 B + l1 A)_local(gather(u))); returns out."""
+  dev = _dev(u, out, enc, geo)
+  ncomp = 1 if u.dim() == 1 else u.shape[-1]
+  np_dt = np.float64 if u.dtype == torch.float64 else np.float32
+  dmat_host = np.ascontiguousarray(dmat_host, dtype=np_dt)
+  args = _lib.HelmholtzArgs(
+      u=u.data_ptr(), out=out.data_ptr(), enc=enc.data_ptr(),
+      geo=geo.data_ptr(), dmat=dmat_host.ctypes.data,
+      num_elements=enc.shape[0], num_nodes=u.shape[0],
+      zero_begin=int(zero_range[0]), zero_end=int(zero_range[1]), ndim=ndim,
+      P=P, ncomp=ncomp, dtype=_dtype_code(u), lambda0=float(lambda0),
+      lambda1=float(lambda1))
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_helmholtz_apply(ctypes.byref(args),
+                                                _stream(dev)),
+               'sfem_helmholtz_apply')
+  return out
+
+
+def helmholtz_local(u_local, geo, dmat_host: np.ndarray, ndim, P, lambda0,
+                    lambda1):
+  u_local = u_local.contiguous()
+  dev = _dev(u_local, geo)
+  ncomp = 1 if u_local.dim() == 2 else u_local.shape[-1]
+  np_dt = np.float64 if u_local.dtype == torch.float64 else np.float32
+  dmat_host = np.ascontiguousarray(dmat_host, dtype=np_dt)
+  out = torch.empty_like(u_local)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_helmholtz_local(
+        _ptr(u_local), _ptr(out), _ptr(geo),
+        ctypes.c_void_p(dmat_host.ctypes.data), u_local.shape[0], ndim, P,
+        ncomp, float(lambda0), float(lambda1), _dtype_code(u_local),
+        _stream(dev)), 'sfem_helmholtz_local')
+  return out
+
+
+# ------------------------------------------------------------------------ CG
+def dot(a, b, result, slot, accumulate=False):
+  """result[slot] (+)= sum(a * b); result is a float64 device tensor."""
+  dev = _dev(a, b, result)
+  fn = (_lib.load().sfem_dot_accumulate if accumulate
+        else _lib.load().sfem_dot)
+  with torch.cuda.device(dev):
+    _lib.check(fn(_ptr(a), _ptr(b), a.numel(),
+                  ctypes.c_void_p(result.data_ptr() + 8 * slot),
+                  _dtype_code(a), _stream(dev)), 'sfem_dot')
+
+
+def cg_scalars(scalars, phase, maxiter, tol, atol):
+  dev = _dev(scalars)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_scalars(
+        _ptr(scalars), phase, float(maxiter), float(tol), float(atol),
+        _stream(dev)), 'sfem_cg_scalars')
+
+
+def cg_update_xr(x, r, p, ap, scalars, fuse_rr):
+  dev = _dev(x, r, p, ap, scalars)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_xr(
+        _ptr(x), _ptr(r), _ptr(p), _ptr(ap), x.numel(), _ptr(scalars),
+        int(fuse_rr), _dtype_code(x), _stream(dev)), 'sfem_cg_update_xr')
+
+
+def cg_update_p(p, z, scalars):
+  dev = _dev(p, z, scalars)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_p(
+        _ptr(p), _ptr(z), p.numel(), _ptr(scalars), _dtype_code(p),
+        _stream(dev)), 'sfem_cg_update_p')
+
+
+def axpby(a, x, b, y):
+  """In place: y = a * x + b * y."""
+  dev = _dev(x, y)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_axpby(
+        float(a), _ptr(x), float(b), _ptr(y), x.numel(), _dtype_code(x),
+        _stream(dev)), 'sfem_axpby')
+  return y

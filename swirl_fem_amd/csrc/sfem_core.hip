@@ -1,0 +1,459 @@
+// libsfem_hip: gather / scatter / exchange / CG vector kernels for gfx950.
+//
+// All of these are HBM-bound streaming or indexed kernels: 64-wide waves,
+// one element of work per lane per iteration with grid-stride loops, 8/16-byte
+// accesses where the layout allows, float atomics only where a sum crosses
+// workgroups.
+#include <stdarg.h>
+#include <string.h>
+
+#include "sfem_common.h"
+
+namespace sfem {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------- gather ---
+template <typename T>
+__global__ void __launch_bounds__(256)
+gather_kernel(const T* __restrict__ u, const int32_t* __restrict__ idx,
+              T* __restrict__ out, int64_t count, T fill) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride) {
+    const int32_t k = idx[i];
+    out[i] = k < 0 ? fill : u[k];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const T* __restrict__ x, const int32_t* __restrict__ idx,
+                   T* __restrict__ out, int64_t count, int ncomp) {
+  const int64_t total = count * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t i = t / ncomp;
+    const int c = (int)(t - i * ncomp);
+    const int32_t k = idx[i];
+    out[t] = k < 0 ? T(0) : x[(int64_t)k * ncomp + c];
+  }
+}
+
+// --------------------------------------------------------------- scatter ---
+template <typename T>
+__global__ void __launch_bounds__(256)
+scatter_add_kernel(const T* __restrict__ u_local,
+                   const int32_t* __restrict__ idx, T* __restrict__ out,
+                   int64_t count, int ncomp) {
+  const int64_t total = count * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t i = t / ncomp;
+    const int c = (int)(t - i * ncomp);
+    const int32_t k = idx[i];
+    if (k >= 0) unsafeAtomicAdd(&out[(int64_t)k * ncomp + c], u_local[t]);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+scatter_csr_kernel(const T* __restrict__ u_local,
+                   const int64_t* __restrict__ offsets,
+                   const int32_t* __restrict__ slots, T* __restrict__ out,
+                   int64_t num_nodes, int ncomp) {
+  const int64_t total = num_nodes * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t v = t / ncomp;
+    const int c = (int)(t - v * ncomp);
+    T acc = T(0);
+    for (int64_t s = offsets[v]; s < offsets[v + 1]; ++s)
+      acc += u_local[(int64_t)slots[s] * ncomp + c];
+    out[t] = acc;
+  }
+}
+
+// -------------------------------------------------------------- exchange ---
+template <typename T>
+__global__ void __launch_bounds__(256)
+exchange_sum_kernel(const T* __restrict__ u, const int32_t* __restrict__ gidx,
+                    const int32_t* __restrict__ unique, T* __restrict__ sums,
+                    int64_t count, int ncomp) {
+  const int64_t total = count * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t i = t / ncomp;
+    const int c = (int)(t - i * ncomp);
+    const int32_t k = gidx[i];
+    if (k >= 0)
+      unsafeAtomicAdd(&sums[(int64_t)unique[i] * ncomp + c],
+                      u[(int64_t)k * ncomp + c]);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+exchange_expand_kernel(const T* __restrict__ sums,
+                       const int32_t* __restrict__ gidx,
+                       const int32_t* __restrict__ unique, T* __restrict__ out,
+                       int64_t count, int ncomp) {
+  const int64_t total = count * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t i = t / ncomp;
+    const int c = (int)(t - i * ncomp);
+    const int32_t k = gidx[i];
+    if (k >= 0)
+      out[(int64_t)k * ncomp + c] = sums[(int64_t)unique[i] * ncomp + c];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+unpack_add_kernel(const T* __restrict__ buf, const int32_t* __restrict__ idx,
+                  T* __restrict__ u, int64_t count, int ncomp) {
+  const int64_t total = count * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t i = t / ncomp;
+    const int c = (int)(t - i * ncomp);
+    const int32_t k = idx[i];
+    if (k >= 0) u[(int64_t)k * ncomp + c] += buf[t];
+  }
+}
+
+// ------------------------------------------------------------ CG kernels ---
+// Block-level sum of one double per thread; one atomic per workgroup.
+__device__ inline double block_sum(double v) {
+  __shared__ double partial[16];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) partial[wave] = v;
+  __syncthreads();
+  double total = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) total += partial[w];
+  }
+  return total;  // valid on thread 0
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+dot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t count,
+           double* __restrict__ result) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride)
+    acc += (double)a[i] * (double)b[i];
+  const double total = block_sum(acc);
+  if (threadIdx.x == 0) unsafeAtomicAdd(result, total);
+}
+
+// scalars (16 doubles): [0] gamma [1] p.Ap [2] gamma_new [3] alpha [4] beta
+//   [5] b.b [6] atol2 [7] done flag (0/1) [8] iterations
+template <typename T, bool FUSE_RR>
+__global__ void __launch_bounds__(512)
+cg_update_xr_kernel(T* __restrict__ x, T* __restrict__ r,
+                    const T* __restrict__ p, const T* __restrict__ ap,
+                    int64_t count, double* __restrict__ scalars) {
+  if (scalars[7] != 0.0) return;  // converged: iteration is a no-op
+  const double alpha_d = scalars[0] / scalars[1];
+  const T alpha = (T)alpha_d;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride) {
+    x[i] += alpha * p[i];
+    const T rn = r[i] - alpha * ap[i];
+    r[i] = rn;
+    if (FUSE_RR) acc += (double)rn * (double)rn;
+  }
+  if (FUSE_RR) {
+    const double total = block_sum(acc);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&scalars[2], total);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+cg_update_p_kernel(T* __restrict__ p, const T* __restrict__ z, int64_t count,
+                   const double* __restrict__ scalars) {
+  if (scalars[7] != 0.0) return;
+  const T beta = (T)(scalars[2] / scalars[0]);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride)
+    p[i] = z[i] + beta * p[i];
+}
+
+// One-thread bookkeeping between the vector kernels of an iteration.
+// phase 2 (init, after b.b -> [5] and gamma0 -> [0]):
+//     atol2 = max(tol^2 b.b, atol^2); clear pAp, iterations;
+//     done <- !(gamma0 > atol2) or maxiter <= 0          (cg.py:65-73)
+// phase 0 (p.Ap accumulated in [1]): alpha = gamma / pAp; clear gamma_new
+// phase 1 (gamma_new accumulated in [2]): beta = gamma_new / gamma;
+//     gamma <- gamma_new; clear pAp; ++iterations;
+//     done <- !(gamma > atol2) or iterations >= maxiter   (cg.py:68-73)
+__global__ void cg_scalar_kernel(double* scalars, int phase, double maxiter,
+                                 double tol, double atol) {
+  if (phase == 2) {
+    const double a = tol * tol * scalars[5], b = atol * atol;
+    scalars[6] = a > b ? a : b;
+    scalars[1] = 0.0;
+    scalars[2] = 0.0;
+    scalars[8] = 0.0;
+    scalars[7] = (!(scalars[0] > scalars[6]) || maxiter <= 0.0) ? 1.0 : 0.0;
+    return;
+  }
+  if (scalars[7] != 0.0) return;
+  if (phase == 0) {
+    scalars[3] = scalars[0] / scalars[1];
+    scalars[2] = 0.0;
+  } else {
+    scalars[4] = scalars[2] / scalars[0];
+    scalars[0] = scalars[2];
+    scalars[1] = 0.0;
+    scalars[8] += 1.0;
+    if (!(scalars[0] > scalars[6]) || scalars[8] >= maxiter) scalars[7] = 1.0;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+axpby_kernel(T a, const T* __restrict__ x, T b, T* __restrict__ y,
+             int64_t count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride)
+    y[i] = a * x[i] + (b == T(0) ? T(0) : b * y[i]);
+}
+
+}  // namespace sfem
+
+using namespace sfem;
+
+#define DISPATCH_DTYPE(dtype, ...)                      \
+  if ((dtype) == SFEM_F64) {                            \
+    using T = double;                                   \
+    __VA_ARGS__;                                        \
+  } else if ((dtype) == SFEM_F32) {                     \
+    using T = float;                                    \
+    __VA_ARGS__;                                        \
+  } else {                                              \
+    set_error("unknown dtype %d", (int)(dtype));        \
+    return SFEM_EINVAL;                                 \
+  }
+
+extern "C" {
+
+int sfem_abi_version(void) { return SFEM_ABI_VERSION; }
+const char* sfem_last_error(void) { return g_error; }
+
+int sfem_gather(const void* u, const int32_t* indices, void* out,
+                int64_t count, double fill, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0, "sfem_gather: negative count");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(u && indices && out, "sfem_gather: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      gather_kernel<T>, dim3(stream_grid(count, 256)), dim3(256), 0,
+      as_stream(stream), (const T*)u, indices, (T*)out, count, (T)fill));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_gather_rows(const void* x, const int32_t* indices, void* out,
+                     int64_t count, int ncomp, int dtype,
+                     sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && ncomp >= 1, "sfem_gather_rows: bad sizes");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(x && indices && out, "sfem_gather_rows: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      gather_rows_kernel<T>, dim3(stream_grid(count * ncomp, 256)), dim3(256),
+      0, as_stream(stream), (const T*)x, indices, (T*)out, count, ncomp));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_scatter_add(const void* u_local, const int32_t* indices, void* out,
+                     int64_t count, int64_t num_nodes, int ncomp, int dtype,
+                     sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && num_nodes >= 0 && ncomp >= 1,
+               "sfem_scatter_add: bad sizes");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_scatter_add: unknown dtype %d", dtype);
+  if (num_nodes == 0) return SFEM_OK;
+  SFEM_REQUIRE(out, "sfem_scatter_add: null out");
+  const size_t esz = dtype == SFEM_F64 ? 8 : 4;
+  SFEM_HIP(hipMemsetAsync(out, 0, (size_t)num_nodes * ncomp * esz,
+                          as_stream(stream)));
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(u_local && indices, "sfem_scatter_add: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      scatter_add_kernel<T>, dim3(stream_grid(count * ncomp, 256)), dim3(256),
+      0, as_stream(stream), (const T*)u_local, indices, (T*)out, count, ncomp));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_scatter_csr(const void* u_local, const int64_t* offsets,
+                     const int32_t* slots, void* out, int64_t num_nodes,
+                     int ncomp, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(num_nodes >= 0 && ncomp >= 1, "sfem_scatter_csr: bad sizes");
+  if (num_nodes == 0) return SFEM_OK;
+  SFEM_REQUIRE(u_local && offsets && slots && out,
+               "sfem_scatter_csr: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      scatter_csr_kernel<T>, dim3(stream_grid(num_nodes * ncomp, 256)),
+      dim3(256), 0, as_stream(stream), (const T*)u_local, offsets, slots,
+      (T*)out, num_nodes, ncomp));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_exchange_local(const void* u, void* out, const int32_t* gidx,
+                        const int32_t* unique, int64_t count,
+                        int64_t num_nodes, void* sums, int64_t num_unique,
+                        int ncomp, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && num_nodes >= 0 && num_unique >= 0 && ncomp >= 1,
+               "sfem_exchange_local: bad sizes");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_exchange_local: unknown dtype %d", dtype);
+  if (num_nodes == 0) return SFEM_OK;
+  SFEM_REQUIRE(u && out, "sfem_exchange_local: null pointer");
+  const size_t esz = dtype == SFEM_F64 ? 8 : 4;
+  if (out != u)
+    SFEM_HIP(hipMemcpyAsync(out, u, (size_t)num_nodes * ncomp * esz,
+                            hipMemcpyDeviceToDevice, as_stream(stream)));
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(gidx && unique && sums, "sfem_exchange_local: null pointer");
+  SFEM_HIP(hipMemsetAsync(sums, 0, (size_t)num_unique * ncomp * esz,
+                          as_stream(stream)));
+  const unsigned grid = stream_grid(count * ncomp, 256);
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(exchange_sum_kernel<T>, dim3(grid), dim3(256), 0,
+                       as_stream(stream), (const T*)u, gidx, unique, (T*)sums,
+                       count, ncomp);
+    hipLaunchKernelGGL(exchange_expand_kernel<T>, dim3(grid), dim3(256), 0,
+                       as_stream(stream), (const T*)sums, gidx, unique,
+                       (T*)out, count, ncomp);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_pack(const void* u, const int32_t* idx, void* buf, int64_t count,
+              int ncomp, int dtype, sfem_stream_t stream) {
+  return sfem_gather_rows(u, idx, buf, count, ncomp, dtype, stream);
+}
+
+int sfem_unpack_add(const void* buf, const int32_t* idx, void* u,
+                    int64_t count, int ncomp, int dtype,
+                    sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && ncomp >= 1, "sfem_unpack_add: bad sizes");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(buf && idx && u, "sfem_unpack_add: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      unpack_add_kernel<T>, dim3(stream_grid(count * ncomp, 256)), dim3(256),
+      0, as_stream(stream), (const T*)buf, idx, (T*)u, count, ncomp));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_dot(const void* a, const void* b, int64_t count, double* result,
+             int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && result, "sfem_dot: bad arguments");
+  SFEM_HIP(hipMemsetAsync(result, 0, sizeof(double), as_stream(stream)));
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(a && b, "sfem_dot: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      dot_kernel<T>, dim3(stream_grid(count, 512 * 4)), dim3(512), 0,
+      as_stream(stream), (const T*)a, (const T*)b, count, result));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_dot_accumulate(const void* a, const void* b, int64_t count,
+                        double* result, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && result, "sfem_dot_accumulate: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(a && b, "sfem_dot_accumulate: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      dot_kernel<T>, dim3(stream_grid(count, 512 * 4)), dim3(512), 0,
+      as_stream(stream), (const T*)a, (const T*)b, count, result));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,
+                      int64_t count, double* scalars, int fuse_rr, int dtype,
+                      sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_xr: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(x && r && p && ap, "sfem_cg_update_xr: null pointer");
+  const unsigned grid = stream_grid(count, 512 * 2);
+  DISPATCH_DTYPE(dtype, {
+    if (fuse_rr)
+      hipLaunchKernelGGL((cg_update_xr_kernel<T, true>), dim3(grid), dim3(512),
+                         0, as_stream(stream), (T*)x, (T*)r, (const T*)p,
+                         (const T*)ap, count, scalars);
+    else
+      hipLaunchKernelGGL((cg_update_xr_kernel<T, false>), dim3(grid),
+                         dim3(512), 0, as_stream(stream), (T*)x, (T*)r,
+                         (const T*)p, (const T*)ap, count, scalars);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_update_p(void* p, const void* z, int64_t count, double* scalars,
+                     int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_p: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(p && z, "sfem_cg_update_p: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      cg_update_p_kernel<T>, dim3(stream_grid(count, 512 * 2)), dim3(512), 0,
+      as_stream(stream), (T*)p, (const T*)z, count, scalars));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
+                    double atol, sfem_stream_t stream) {
+  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 2,
+               "sfem_cg_scalars: bad arguments");
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, as_stream(stream),
+                     scalars, phase, maxiter, tol, atol);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_axpby(double a, const void* x, double b, void* y, int64_t count,
+               int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0, "sfem_axpby: negative count");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(x && y, "sfem_axpby: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      axpby_kernel<T>, dim3(stream_grid(count, 512 * 2)), dim3(512), 0,
+      as_stream(stream), (T)a, (const T*)x, (T)b, (T*)y, count));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+}  // extern "C"

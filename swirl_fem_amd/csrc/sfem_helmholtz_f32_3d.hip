@@ -1,0 +1,5 @@
+// Instantiations of the fused Helmholtz kernel: float, 3D, P = 2..12.
+#include "sfem_helmholtz.h"
+namespace sfem {
+SFEM_DEFINE_HELMHOLTZ_DISPATCH(float, 3)
+}  // namespace sfem

@@ -1,0 +1,141 @@
+"""Block partitions of a structured hex mesh, built rank-locally.
+
+The reference partitions by regrouping the *global* element list
+(`Premesh.finalize(axis_name)`, core/premesh.py:170-222, with block partitions
+from `unit_cube_mesh(partitions=...)`, common/premesh_commons.py:130-138) and
+derives a dense `(P, S)` table of all shared DOFs
+(core/gather_scatter.py:318-358).  That is O(global mesh) work on one host and
+does not scale to 128^3 elements at p = 7 (0.7 G nodes).
+
+Here every rank builds only its own `n^3`-element block -- same generator, same
+refiner, same local numbering as an unpartitioned mesh of that block -- and
+finds the DOFs it shares with each of its (up to 26) neighbour blocks from the
+global GLL lattice coordinates of its surface nodes.  Both sides of a pair sort
+the shared DOFs by the same global lattice key, so no setup communication is
+needed.  The result is the `NeighborPlan` consumed by
+`distributed.comm.neighbor_exchange` (QQ^T over RCCL).
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import itertools
+
+import numpy as np
+import torch
+
+from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+from swirl_fem_amd.core.interpolation import Nodes1D
+from swirl_fem_amd.core.interpolation import NodeType
+from swirl_fem_amd.core.mesh import Mesh
+from swirl_fem_amd.core.mesh_refiner import refine_premesh
+from swirl_fem_amd.distributed import comm
+
+
+@dataclasses.dataclass(eq=False)
+class BlockPartition:
+  mesh: Mesh
+  rank: int
+  block_grid: tuple
+  block_coords: tuple
+  num_global_nodes: int
+  plan: comm.NeighborPlan
+
+  def reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+    """All-reduce of CG scalars across the partitions (RCCL)."""
+    return comm.all_reduce_sum_(t)
+
+
+def build_block_partition(n: int, P: int, block_grid, rank: int, *,
+                          device=None, dtype=torch.float64, lo=0.0, hi=1.0,
+                          jitter: float = 0.0) -> BlockPartition:
+  """This rank's block of the `(n*px, n*py, n*pz)`-element mesh on [lo,hi]^3.
+
+  Args:
+    n: elements per direction in one block.
+    P: GLL nodes per direction (order + 1).
+    block_grid: (px, py, pz) blocks; rank = C-order ravel of block coords.
+    jitter: optional smooth deformation amplitude (fraction of h), identical on
+      all ranks because it is a function of the global coordinates.
+  """
+  ndim = len(block_grid)
+  block_grid = tuple(int(p) for p in block_grid)
+  coords_b = tuple(int(c) for c in np.unravel_index(rank, block_grid))
+  pm = unit_cube_mesh(n, ndim=ndim)
+  # affine map of the unit block into its slot of the global box
+  x = np.array(pm.node_coords)
+  for d in range(ndim):
+    x[:, d] = lo + (hi - lo) * (coords_b[d] + x[:, d]) / block_grid[d]
+  if jitter:
+    h = (hi - lo) / (n * max(block_grid))
+    s = np.ones(len(x))
+    for d in range(ndim):
+      s = s * np.sin(np.pi * (x[:, d] - lo) / (hi - lo))
+    x = x + jitter * h * s[:, None] * np.cos(
+        2 * np.pi * x[:, ::-1] / (hi - lo))
+  # keep only the faces that lie on the global boundary
+  nf = n ** (ndim - 1)
+  faces = pm.physical_groups['boundary'].reshape(ndim, 2, nf, -1)
+  keep = []
+  for d in range(ndim):
+    if coords_b[d] == 0:
+      keep.append(faces[d, 0])
+    if coords_b[d] == block_grid[d] - 1:
+      keep.append(faces[d, 1])
+  groups = {'boundary': np.concatenate(keep)} if keep else {}
+  pm = pm.replace(node_coords=x, physical_groups=groups)
+  rp = refine_premesh(pm, Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE))
+
+  # block-local GLL lattice coordinates of every local node
+  m = P - 1
+  L = n * m                                   # last lattice index per dim
+  ecoord = np.stack(np.meshgrid(*([np.arange(n)] * ndim), indexing='ij'),
+                    axis=-1).reshape(-1, ndim)              # (E, d)
+  lcoord = np.stack(np.meshgrid(*([np.arange(P)] * ndim), indexing='ij'),
+                    axis=-1).reshape(-1, ndim)              # (n_loc, d)
+  lat = np.zeros((rp.num_nodes, ndim), dtype=np.int32)
+  flat = rp.elements.reshape(-1)
+  for d in range(ndim):
+    vals = (ecoord[:, None, d] * m + lcoord[None, :, d]).reshape(-1)
+    lat[flat, d] = vals
+  glob = lat.astype(np.int64) + np.array(coords_b, dtype=np.int64) * L
+  gdims = [block_grid[d] * L + 1 for d in range(ndim)]
+  key = np.ravel_multi_index(tuple(glob[:, d] for d in range(ndim)), gdims)
+
+  neighbors, indices = [], []
+  for off in itertools.product((-1, 0, 1), repeat=ndim):
+    if not any(off):
+      continue
+    nb = tuple(c + o for c, o in zip(coords_b, off))
+    if any(c < 0 or c >= g for c, g in zip(nb, block_grid)):
+      continue
+    sel = np.ones(rp.num_nodes, dtype=bool)
+    for d, o in enumerate(off):
+      if o == -1:
+        sel &= lat[:, d] == 0
+      elif o == 1:
+        sel &= lat[:, d] == L
+    pos = np.nonzero(sel)[0]
+    pos = pos[np.argsort(key[pos], kind='stable')]
+    neighbors.append(int(np.ravel_multi_index(nb, block_grid)))
+    indices.append(pos.astype(np.int32))
+  # several offsets never map to the same rank without periodic wrap-around
+  assert len(set(neighbors)) == len(neighbors)
+  order = np.argsort(neighbors)
+  plan = comm.NeighborPlan(rank=rank, neighbors=[neighbors[i] for i in order],
+                           indices=[indices[i] for i in order])
+
+  arrays = rp.finalize_all()
+  world = int(np.prod(block_grid))
+  mesh = Mesh.create(
+      gridpoints_1d=rp.gridpoints_1d, device=device, dtype=dtype,
+      axis_name='blocks' if world > 1 else None,
+      neighbor_plan=plan if world > 1 else None, **{
+          k: v for k, v in arrays.items()
+          if k in ('node_coords', 'elements', 'node_indices', 'physical_masks')
+      },
+      exchange_gather_indices=(np.concatenate(indices).astype(np.int32)
+                               if world > 1 and indices else None))
+  return BlockPartition(mesh=mesh, rank=rank, block_grid=block_grid,
+                        block_coords=coords_b,
+                        num_global_nodes=int(np.prod(gdims)), plan=plan)

@@ -1,0 +1,125 @@
+"""Partitioned shared-DOF exchange: RCCL neighbour send/recv over xGMI.
+
+Replaces the one collective on the reference's hot path: `lax.psum` of a dense
+vector of ALL globally shared DOFs inside `gather_scatter.exchange`
+(core/gather_scatter.py:247-248, indices built at :318-358).  A ring
+all-reduce of that vector moves 2 (P-1)/P S values through every GPU and is
+bound by one ~153 GB/s xGMI link; here each shared DOF travels only to the
+ranks that hold a copy, as one packed message per neighbour, and the (up to 7)
+point-to-point links of a GPU are used in parallel:
+
+    pack (HIP gather)  ->  grouped ncclSend/ncclRecv  ->  unpack-add (HIP)
+
+One process owns one partition (`torch.distributed`, backend "nccl" = RCCL on
+ROCm; "gloo" in the CPU tests).  The result is bit-for-bit QQ^T u: every rank
+adds the *original* values of all other holders of a DOF to its own.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def get_rank() -> int:
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_rank()
+  return int(os.environ.get('RANK', '0'))
+
+
+def get_world_size() -> int:
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_world_size()
+  return int(os.environ.get('WORLD_SIZE', '1'))
+
+
+@dataclasses.dataclass(eq=False)
+class NeighborPlan:
+  """Per-neighbour lists of local positions of the DOFs shared with it.
+
+  `neighbors[i]` is a rank; `indices[i]` the local node positions (host int32
+  array) of the DOFs shared with that rank, ordered by global shared-DOF id so
+  that both sides enumerate them identically.
+  """
+  rank: int
+  neighbors: list
+  indices: list
+  _dev: dict = dataclasses.field(default_factory=dict, repr=False)
+
+  @classmethod
+  def from_gather_indices(cls, gather_indices: np.ndarray,
+                          rank: int) -> 'NeighborPlan':
+    """From the reference-style `(P, S)` table (-1 = rank lacks the DOF)."""
+    gi = np.asarray(gather_indices)
+    mine = gi[rank] >= 0
+    neighbors, indices = [], []
+    for q in range(gi.shape[0]):
+      if q == rank:
+        continue
+      both = mine & (gi[q] >= 0)
+      if both.any():
+        neighbors.append(q)
+        indices.append(gi[rank, both].astype(np.int32))
+    return cls(rank=rank, neighbors=neighbors, indices=indices)
+
+  def device_indices(self, device):
+    key = str(device)
+    if key not in self._dev:
+      self._dev[key] = [torch.as_tensor(ix, dtype=torch.int32, device=device)
+                        for ix in self.indices]
+    return self._dev[key]
+
+  @property
+  def num_shared(self) -> int:
+    return int(sum(len(ix) for ix in self.indices))
+
+
+def exchange_buffers(plan: NeighborPlan, send_bufs, group=None):
+  """Sends `send_bufs[i]` to `plan.neighbors[i]` and returns what they sent.
+
+  One grouped batch of P2P ops (RCCL: ncclGroupStart ... ncclGroupEnd), so all
+  neighbour links are driven concurrently.
+  """
+  recv_bufs = [torch.empty_like(b) for b in send_bufs]
+  if not plan.neighbors:
+    return recv_bufs
+  ops = []
+  for q, sb, rb in zip(plan.neighbors, send_bufs, recv_bufs):
+    ops.append(dist.P2POp(dist.isend, sb, q, group=group))
+    ops.append(dist.P2POp(dist.irecv, rb, q, group=group))
+  for req in dist.batch_isend_irecv(ops):
+    req.wait()
+  return recv_bufs
+
+
+def neighbor_exchange(u: torch.Tensor, plan: NeighborPlan, group=None, *,
+                      pack_fn=None, unpack_add_fn=None) -> torch.Tensor:
+  """QQ^T u for this rank's partition.
+
+  `pack_fn` / `unpack_add_fn` default to the HIP kernels (`sfem_pack`,
+  `sfem_unpack_add`); they exist as parameters only so that the CPU (gloo)
+  tests can exercise the communication pattern with the oracle's gather /
+  scatter as the checker.
+  """
+  if pack_fn is None or unpack_add_fn is None:
+    from swirl_fem_amd import _ops
+    pack_fn = pack_fn or _ops.pack
+    unpack_add_fn = unpack_add_fn or _ops.unpack_add
+  idx = plan.device_indices(u.device)
+  send = [pack_fn(u, ix) for ix in idx]
+  recv = exchange_buffers(plan, send, group=group)
+  out = u.clone()
+  for rb, ix in zip(recv, idx):
+    unpack_add_fn(rb, ix, out)
+  return out
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+  """In-place sum over ranks (the CG scalars; one fused all-reduce)."""
+  if dist.is_available() and dist.is_initialized() and get_world_size() > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+  return t

@@ -1,0 +1,545 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs the CPU oracle.
+
+fp64 tolerance 1e-10 relative, fp32 1e-5 relative (BASELINE.json north_star).
+Every test here needs a real MI355X: run with `pytest -m gpu`.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sfem_oracle as O
+from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+from swirl_fem_amd.core import gather_scatter
+from swirl_fem_amd.core.fespace import FiniteElementSpace, div, grad
+from swirl_fem_amd.core.interpolation import (Nodes1D, NodeType, Quadrature1D)
+from swirl_fem_amd.core.mesh import Mesh
+from swirl_fem_amd.core.mesh_refiner import refine_premesh
+from swirl_fem_amd.core.premesh import Premesh
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+NT = {'gll': NodeType.GAUSS_LOBATTO_LEGENDRE, 'gl': NodeType.GAUSS_LEGENDRE,
+      'nc': NodeType.NEWTON_COTES}
+TOL = {torch.float64: 1e-10, torch.float32: 1e-5}
+
+
+def relerr(a, b):
+  a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+  b = np.asarray(b)
+  assert a.shape == b.shape, (a.shape, b.shape)
+  return np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def dev(x, dtype=None):
+  t = torch.as_tensor(np.ascontiguousarray(x), device=DEV)
+  return t if dtype is None else t.to(dtype)
+
+
+def make_case(ndim, n, P, jitter=0.1, seed=0, periodic=(), scramble=False):
+  """Deformed structured mesh refined to GLL P; returns (refined premesh)."""
+  rng = np.random.default_rng(seed)
+  pm = unit_cube_mesh(n, ndim=ndim, periodic_dims=periodic)
+  if jitter and not periodic:
+    h = 1.0 / n
+    pm = pm.replace(node_coords=pm.node_coords + jitter * h *
+                    rng.uniform(-1, 1, pm.node_coords.shape))
+  if scramble:
+    pm = pm.replace(elements=pm.elements[rng.permutation(pm.num_elements)])
+  return refine_premesh(pm, Nodes1D.create(P, NT['gll']))
+
+
+def spaces(rp, P, q, qt, dtype=torch.float64):
+  mesh = rp.finalize(device=DEV, dtype=dtype)
+  quad = Quadrature1D.create(q, NT[qt])
+  fes = FiniteElementSpace.create(mesh, quad)
+  ofes = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'), (q, qt))
+  return mesh, fes, ofes
+
+
+# ---------------------------------------------------------- gather / scatter
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_gather_scatter_sentinel(dtype):
+  rng = np.random.default_rng(1)
+  N, E, n = 1000, 300, 27
+  idx = rng.integers(0, N, (E, n)).astype(np.int32)
+  idx[rng.random((E, n)) < 0.1] = -1
+  idx[-1, :] = -1                      # a fully padded element
+  u = rng.standard_normal(N)
+  got = gather_scatter.gather(dev(u, dtype), dev(idx), fill_value=0.)
+  assert relerr(got, O.gather(u, idx, 0.)) < TOL[dtype]
+  got = gather_scatter.gather(dev(u, dtype), dev(idx))   # fill = SENTINEL
+  assert relerr(got, O.gather(u, idx)) < TOL[dtype]
+  ul = rng.standard_normal((E, n))
+  got = gather_scatter.scatter(dev(ul, dtype), dev(idx), N)
+  assert relerr(got, O.scatter(ul, idx, N)) < 10 * TOL[dtype]
+  with pytest.raises(ValueError):
+    gather_scatter.gather(dev(ul, dtype), dev(idx))
+
+
+def test_gather_scatter_empty_and_cpu_rejected():
+  idx = torch.zeros((0, 8), dtype=torch.int32, device=DEV)
+  u = torch.zeros(5, dtype=torch.float64, device=DEV)
+  assert gather_scatter.gather(u, idx).shape == (0, 8)
+  out = gather_scatter.scatter(torch.zeros((0, 8), dtype=torch.float64,
+                                           device=DEV), idx, 5)
+  assert out.shape == (5,) and float(out.abs().max()) == 0.0
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    gather_scatter.gather(torch.zeros(5, dtype=torch.float64),
+                          torch.zeros(3, dtype=torch.int32))
+
+
+def test_scatter_csr_deterministic():
+  from swirl_fem_amd import _ops
+  rp = make_case(3, 3, 4)
+  mesh = rp.finalize(device=DEV)
+  rng = np.random.default_rng(2)
+  ul = rng.standard_normal(rp.elements.shape)
+  off, slots = mesh.assembly_plan().csr()
+  a = _ops.scatter_csr(dev(ul), off, slots, mesh.num_nodes)
+  b = _ops.scatter_csr(dev(ul), off, slots, mesh.num_nodes)
+  assert torch.equal(a, b)
+  assert relerr(a, O.scatter(ul, rp.elements, mesh.num_nodes)) < 1e-13
+
+
+def test_mesh_gather_scatter_element_coords():
+  rp = make_case(2, 4, 3)
+  mesh = rp.finalize(device=DEV)
+  u = np.random.default_rng(3).standard_normal(mesh.num_nodes)
+  assert relerr(mesh.gather(dev(u)), u[rp.elements]) == 0.0
+  assert relerr(mesh.element_coords(), rp.node_coords[rp.elements]) == 0.0
+  with pytest.raises(ValueError):
+    mesh.gather(dev(u[:-1]))
+
+
+# ------------------------------------------------------------------ exchange
+def test_exchange_reference_known_answers():
+  # core/gather_scatter_test.py:50-130 and core/premesh_test.py:79-176
+  ni = gather_scatter.get_unique_node_indices(
+      np.arange(3, dtype=np.int32), np.array([[[0], [2]]]))
+  gi, ui = gather_scatter.get_exchange_indices(ni)
+  out = gather_scatter.exchange(dev(np.array([1., 2., 3.])), dev(gi), ui)
+  np.testing.assert_allclose(out.cpu().numpy(), [4., 2., 4.])
+  links = np.array([[[0, 1], [6, 7]], [[1, 2], [7, 8]], [[0, 3], [2, 5]],
+                    [[3, 6], [5, 8]]], dtype=np.int32)
+  ni = gather_scatter.get_unique_node_indices(np.arange(9, dtype=np.int32),
+                                              links)
+  gi, ui = gather_scatter.get_exchange_indices(ni)
+  out = gather_scatter.exchange(dev(np.arange(9.)), dev(gi), ui)
+  np.testing.assert_allclose(out.cpu().numpy(),
+                             [16., 8., 16., 8., 4., 8., 16., 8., 16.])
+  # premesh_test.py:128-176
+  coords = np.array([[0, 0], [0, 1], [1, 0], [1, 1], [0, 2], [2, 1]], float)
+  elements = np.array([[0, 1, 2, 3], [2, 3, 4, 5]], dtype=np.int32)
+  pm = Premesh.create(coords, elements,
+                      periodic_links=np.array([[[0, 1], [4, 5]]], np.int32))
+  mesh = pm.finalize(device=DEV)
+  out = mesh.exchange(dev(1. + np.arange(6.)))
+  np.testing.assert_allclose(out.cpu().numpy(), [6, 8, 3, 4, 6, 8])
+  pm = Premesh.create(coords, elements, periodic_links=np.array(
+      [[[0, 1], [4, 5]], [[0, 2], [1, 3]], [[2, 4], [3, 5]]], np.int32))
+  out = pm.finalize(device=DEV).exchange(dev(np.ones(6)))
+  np.testing.assert_allclose(out.cpu().numpy(), [4, 4, 2, 2, 4, 4])
+  # no-op cases
+  pm = Premesh.create(coords, elements)
+  out = pm.finalize(device=DEV).exchange(dev(np.arange(6.)))
+  np.testing.assert_allclose(out.cpu().numpy(), np.arange(6.))
+
+
+@pytest.mark.parametrize('ndim,per', [(2, (0,)), (2, (0, 1)), (3, (0, 1, 2))])
+def test_exchange_periodic_refined(ndim, per):
+  rp = make_case(ndim, 3, 4, periodic=per)
+  mesh = rp.finalize(device=DEV)
+  arrs = rp.finalize_all()
+  u = np.random.default_rng(4).standard_normal(mesh.num_nodes)
+  ref = O.exchange_unpartitioned(u, arrs['exchange_gather_indices'],
+                                 arrs['exchange_unique_indices'])
+  assert relerr(mesh.exchange(dev(u)), ref) < 1e-14
+  # idempotence up to multiplicity: exchanging a constant counts the images
+  ones = mesh.exchange(dev(np.ones(mesh.num_nodes)))
+  ref1 = O.exchange_unpartitioned(np.ones(mesh.num_nodes),
+                                  arrs['exchange_gather_indices'],
+                                  arrs['exchange_unique_indices'])
+  assert relerr(ones, ref1) == 0.0
+
+
+# ---------------------------------------------------- geometry and basis eval
+CASES = [  # ndim, n, P, q, quadrature type
+    (1, 5, 4, 5, 'gl'), (2, 3, 4, 5, 'gl'), (2, 3, 5, 5, 'gll'),
+    (2, 2, 6, 8, 'gll'), (3, 2, 3, 4, 'gl'), (3, 2, 4, 4, 'gll'),
+    (3, 2, 4, 6, 'gll'), (3, 2, 6, 4, 'gll'),
+]
+
+
+@pytest.mark.parametrize('ndim,n,P,q,qt', CASES)
+def test_geometric_factors(ndim, n, P, q, qt):
+  rp = make_case(ndim, n, P, seed=5)
+  _, fes, ofes = spaces(rp, P, q, qt)
+  assert relerr(fes.invjacs, ofes.invjacs) < 1e-10
+  assert relerr(fes.jacdets, ofes.jacdets) < 1e-10
+  assert relerr(fes.quad_coords, ofes.quad_coords) < 1e-12
+
+
+def test_signed_jacobian_of_reflected_element():
+  # a mirrored element has negative det J and the reference keeps the sign
+  coords = np.array([[1., 0], [1, 1], [0, 0], [0, 1]])
+  mesh = Mesh.create(coords, np.arange(4).reshape(1, 4), device=DEV)
+  fes = FiniteElementSpace.create(mesh, Quadrature1D.create(2, NT['gl']))
+  ofes = O.FESpace(coords, np.arange(4).reshape(1, 4), (2, 'nc'), (2, 'gl'))
+  assert float(fes.jacdets.max()) < 0
+  assert relerr(fes.jacdets, ofes.jacdets) < 1e-13
+
+
+@pytest.mark.parametrize('ndim,n,P,q,qt', CASES)
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_qfunction_values_and_gradients(ndim, n, P, q, qt, dtype):
+  rp = make_case(ndim, n, P, seed=6)
+  mesh, fes, ofes = spaces(rp, P, q, qt, dtype)
+  rng = np.random.default_rng(7)
+  tol = TOL[dtype] * (1 if dtype == torch.float64 else 30)
+  us = rng.standard_normal(rp.elements.shape)
+  f = fes.scalar_function(dev(us, dtype))
+  assert relerr(f(None).val, ofes.value(us)) < tol
+  assert relerr(grad(f)(None).val, ofes.grad(us)) < tol
+  uv = rng.standard_normal(rp.elements.shape + (ndim,))
+  fv = fes.vector_function(dev(uv, dtype))
+  assert relerr(fv(None).val, ofes.value(uv)) < tol
+  assert relerr(grad(fv)(None).val, ofes.grad(uv)) < tol
+  ig = fes.integrate(lambda x: torch.vdot(grad(f)(x), grad(f)(x)))
+  ref = ofes.integrate(np.einsum('mqj,mqj->mq', ofes.grad(us), ofes.grad(us)))
+  assert abs(float(ig) - ref) < 30 * tol * abs(ref)
+
+
+# ------------------------------------------------------- forms / local_covector
+@pytest.mark.parametrize('ndim,n,P,q,qt', CASES[1:])
+def test_local_covector_forms(ndim, n, P, q, qt):
+  rp = make_case(ndim, n, P, seed=8)
+  mesh, fes, ofes = spaces(rp, P, q, qt)
+  rng = np.random.default_rng(9)
+  us = rng.standard_normal(rp.elements.shape)
+  uv = rng.standard_normal(rp.elements.shape + (ndim,))
+  wv = rng.standard_normal(rp.elements.shape + (ndim,))
+
+  u, v = fes.scalar_function(dev(us)), fes.scalar_function(None)
+  mass = fes.local_covector(lambda a, b: lambda x: a(x) * b(x), (u, v))
+  assert relerr(mass, ofes.mass_local(us)) < 1e-10
+  stiff = fes.local_covector(
+      lambda a, b: lambda x: torch.vdot(grad(a)(x), grad(b)(x)), (u, v))
+  assert relerr(stiff, ofes.stiffness_local(us)) < 1e-10
+
+  U, V = fes.vector_function(dev(uv)), fes.vector_function(None)
+  vmass = fes.local_covector(
+      lambda a, b: lambda x: torch.vdot(a(x), b(x)), (U, V))
+  assert relerr(vmass, ofes.mass_local(uv)) < 1e-10
+  vstiff = fes.local_covector(
+      lambda a, b: lambda x: torch.einsum('ij,ij->', grad(a)(x), grad(b)(x)),
+      (U, V))
+  assert relerr(vstiff, ofes.stiffness_local(uv)) < 1e-10
+  W = fes.vector_function(dev(wv))
+  conv = fes.local_covector(
+      lambda a, w, b: lambda x: torch.einsum('i,ij,j->', a(x), grad(w)(x),
+                                             b(x)), (U, W, V))
+  assert relerr(conv, ofes.convection_local(uv, wv)) < 1e-10
+  # placeholder in the first slot (symmetric form) gives the same covector
+  stiff2 = fes.local_covector(
+      lambda a, b: lambda x: torch.vdot(grad(a)(x), grad(b)(x)), (v, u))
+  assert relerr(stiff2, ofes.stiffness_local(us)) < 1e-10
+  with pytest.raises(ValueError):
+    fes.local_covector(lambda a, b: lambda x: a(x) * b(x), (u, u))
+  with pytest.raises(ValueError):
+    fes.scalar_function(dev(us[:, :-1]))
+
+
+@pytest.mark.parametrize('ndim,n,P', [(2, 3, 6), (3, 2, 5)])
+def test_divergence_forms_mixed_spaces(ndim, n, P):
+  # P_N - P_{N-2}: velocity GLL(P), pressure GL(P-2), shared GLL(P) quadrature
+  # (navier_stokes.py:117-121, :279-282, :313-329)
+  rng = np.random.default_rng(10)
+  pm = unit_cube_mesh(n, ndim=ndim)
+  pm = pm.replace(node_coords=pm.node_coords + 0.05 *
+                  rng.uniform(-1, 1, pm.node_coords.shape))
+  vgrid, pgrid = Nodes1D.create(P, NT['gll']), Nodes1D.create(P - 2, NT['gl'])
+  rv, rq = refine_premesh(pm, vgrid), refine_premesh(pm, pgrid)
+  quad = Quadrature1D.create(P, NT['gll'])
+  vsp = FiniteElementSpace.create(rv.finalize(device=DEV), quad)
+  psp = FiniteElementSpace.create(rq.finalize(device=DEV), quad)
+  ov = O.FESpace(rv.node_coords, rv.elements, (P, 'gll'), (P, 'gll'))
+  op = O.FESpace(rq.node_coords, rq.elements, (P - 2, 'gl'), (P, 'gll'))
+  b = lambda vf, qf: lambda x: div(vf)(x) * qf(x)
+  uv = rng.standard_normal(rv.elements.shape + (ndim,))
+  pl = rng.standard_normal(rq.elements.shape)
+  d_local = psp.local_covector(
+      b, (vsp.vector_function(dev(uv)), psp.scalar_function(None)))
+  assert relerr(d_local, O.div_local(ov, op, uv)) < 1e-10
+  dt_local = vsp.local_covector(
+      b, (vsp.vector_function(None), psp.scalar_function(dev(pl))))
+  assert relerr(dt_local, O.div_t_local(ov, op, pl)) < 1e-10
+  # adjointness: <D u, p> == <u, D^T p>
+  lhs = float((d_local * dev(pl)).sum())
+  rhs = float((dt_local * dev(uv)).sum())
+  assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+
+
+def test_fespace_reference_known_answers():
+  # core/fespace_test.py:128-180 (skewed quad) and :73-126 (single elements)
+  coords = np.array([[0, 0], [0, 1], [1, 0], [1, 2]], dtype=np.float64)
+  mesh = Mesh.create(coords, np.arange(4).reshape(1, 4), device=DEV)
+  fes = FiniteElementSpace.create(mesh, Quadrature1D.create(2, NT['gl']))
+  xe = mesh.element_coords()
+  f = fes.scalar_function(2 * xe[..., 0] - xe[..., 1] + 1)
+  assert float(fes.integrate(lambda x: grad(f)(x)[0])) == pytest.approx(3.0)
+  assert float(fes.integrate(lambda x: grad(f)(x)[1])) == pytest.approx(-1.5)
+  fv = fes.vector_function(torch.stack(
+      [2 * xe[..., 0] - xe[..., 1], 3 * xe[..., 1]], dim=-1))
+  assert float(fes.integrate(div(fv))) == pytest.approx(7.5)
+  for ndim in (1, 2, 3):
+    for order in (1, 2, 3, 4):
+      n = (order + 1) ** ndim
+      c1 = np.linspace(0, 1, order + 1)
+      cc = np.stack(np.meshgrid(*([c1] * ndim), indexing='ij'),
+                    axis=-1).reshape(n, ndim)
+      m = Mesh.create(cc, np.arange(n).reshape(1, n), device=DEV)
+      fs = FiniteElementSpace.create(m, Quadrature1D.create(order + 1,
+                                                            NT['gl']))
+      fn = lambda x: sum(x[i] ** order for i in range(ndim))
+      assert float(fs.integrate(fn)) == pytest.approx(ndim / (1 + order))
+      assert float(fs.integrate(lambda x: grad(fn)(x)[0])) == pytest.approx(1.)
+      ec = m.element_coords()
+      nodal = fs.scalar_function((ec ** order).sum(-1))
+      assert float(fs.integrate(nodal)) == pytest.approx(ndim / (1 + order))
+      assert float(fs.integrate(lambda x: grad(nodal)(x)[0])) == pytest.approx(
+          1.)
+  assert float(fes.integrate(lambda x: 1.)) == pytest.approx(1.5)
+
+
+# ------------------------------------------------- fused Helmholtz operator
+def _helmholtz_ref(ofes, u, l0, l1, dirichlet):
+  ul = ofes.gather(u)
+  loc = 0.0
+  if l0:
+    loc = loc + l0 * ofes.mass_local(ul)
+  if l1:
+    loc = loc + l1 * ofes.stiffness_local(ul)
+  out = ofes.scatter(loc)
+  if dirichlet is not None:
+    keep = 1.0 - dirichlet.astype(np.float64)
+    out = out * (keep if out.ndim == 1 else keep[:, None])
+  return out
+
+
+@pytest.mark.parametrize('ndim,n,P', [
+    (2, 4, 2), (2, 3, 3), (2, 3, 4), (2, 3, 5), (2, 2, 7), (2, 2, 8),
+    (2, 2, 11), (2, 2, 12), (3, 3, 2), (3, 2, 3), (3, 3, 4), (3, 2, 5),
+    (3, 2, 6), (3, 2, 7), (3, 3, 8), (3, 2, 9), (3, 2, 10), (3, 1, 11),
+    (3, 2, 12)])
+def test_fused_helmholtz_fp64(ndim, n, P):
+  rp = make_case(ndim, n, P, seed=11, scramble=True)
+  mesh, fes, ofes = spaces(rp, P, P, 'gll')
+  rng = np.random.default_rng(12)
+  u = rng.standard_normal(mesh.num_nodes)
+  bmask = mesh.physical_masks['boundary'].cpu().numpy()
+  op_free = fes.helmholtz_operator(None)
+  op_bc = fes.helmholtz_operator(mesh.physical_masks['boundary'])
+  for l0, l1, op, msk in [(0., 1., op_free, None), (1., 0., op_free, None),
+                          (0.7, 1.3, op_bc, bmask)]:
+    got = op.apply(dev(u), l0, l1)
+    assert relerr(got, _helmholtz_ref(ofes, u, l0, l1, msk)) < 1e-10, (l0, l1)
+  ul = rng.standard_normal(rp.elements.shape)
+  got = op_free.apply_local(dev(ul), 0.3, 2.0)
+  ref = 0.3 * ofes.mass_local(ul) + 2.0 * ofes.stiffness_local(ul)
+  assert relerr(got, ref) < 1e-10
+  # constants are in the nullspace of the stiffness operator
+  z = op_free.apply(dev(np.ones(mesh.num_nodes)), 0., 1.)
+  assert float(z.abs().max()) < 1e-9 * float(np.abs(
+      _helmholtz_ref(ofes, u, 0., 1., None)).max())
+
+
+@pytest.mark.parametrize('ndim,n,P', [(2, 3, 6), (3, 2, 4), (3, 2, 8),
+                                      (3, 1, 12)])
+def test_fused_helmholtz_fp32_and_vector(ndim, n, P):
+  rp = make_case(ndim, n, P, seed=13)
+  rng = np.random.default_rng(14)
+  for dtype in (torch.float32, torch.float64):
+    mesh, fes, ofes = spaces(rp, P, P, 'gll', dtype)
+    op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
+    bmask = mesh.physical_masks['boundary'].cpu().numpy()
+    tol = 1e-10 if dtype == torch.float64 else 2e-5
+    for nc in (1, 2, 3):
+      u = rng.standard_normal((mesh.num_nodes, nc))
+      uu = u[:, 0] if nc == 1 else u
+      got = op.apply(dev(uu, dtype), 0.5, 1.5)
+      assert relerr(got, _helmholtz_ref(ofes, uu, 0.5, 1.5, bmask)) < tol
+    ul = rng.standard_normal(rp.elements.shape + (ndim,))
+    got = op.apply_local(dev(ul, dtype), 0.0, 1.0)
+    assert relerr(got, ofes.stiffness_local(ul)) < tol
+
+
+def test_fused_helmholtz_padded_elements_and_errors():
+  # partition-style padding: trailing elements with all -1 connectivity
+  rp = make_case(3, 2, 4, seed=15)
+  elements = np.concatenate([rp.elements, np.full((3, 64), -1, np.int32)])
+  mesh = Mesh.create(rp.node_coords, elements,
+                     gridpoints_1d=rp.gridpoints_1d, device=DEV)
+  fes = FiniteElementSpace.create(
+      mesh, Quadrature1D.create_from_nodes_1d(rp.gridpoints_1d))
+  ofes = O.FESpace(rp.node_coords, rp.elements, (4, 'gll'), (4, 'gll'))
+  u = np.random.default_rng(16).standard_normal(mesh.num_nodes)
+  got = fes.helmholtz_operator(None).apply(dev(u), 0.2, 1.0)
+  assert torch.isfinite(got).all()
+  assert relerr(got, _helmholtz_ref(ofes, u, 0.2, 1.0, None)) < 1e-10
+  # non-collocated spaces have no fused kernel
+  fes2 = FiniteElementSpace.create(mesh, Quadrature1D.create(5, NT['gl']))
+  with pytest.raises(NotImplementedError):
+    fes2.helmholtz_operator(None)
+  with pytest.raises(ValueError):
+    fes.helmholtz_operator(None).apply(dev(u[:-1]))
+
+
+# ----------------------------------------------------------------------- CG
+def test_cg_reference_known_answers():
+  from swirl_fem_amd.linalg.cg import cg
+  b = dev(np.arange(9.0).reshape(3, 3))
+  x, info = cg(lambda x: 2 * x, b)
+  np.testing.assert_allclose(x.cpu().numpy(), np.arange(9.).reshape(3, 3) / 2)
+  assert info['num_iterations'] == 1
+  A = lambda x: {'a': x['a'] + 0.5 * x['b'], 'b': 0.5 * x['a'] + x['b']}
+  x, _ = cg(A, {'a': dev(np.array([1.0])), 'b': dev(np.array([-4.0]))})
+  assert float(x['a']) == pytest.approx(4.0, abs=1e-6)
+  assert float(x['b']) == pytest.approx(-6.0, abs=1e-6)
+  A = lambda x: torch.stack([2 * x[0], 0 * x[1]])
+  M = lambda x: torch.stack([x[0], 0 * x[1]])
+  x, _ = cg(A, dev(1 + np.arange(2.0)), M=M)
+  np.testing.assert_allclose(x.cpu().numpy(), [0.5, 0.])
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    cg(lambda x: x, torch.ones(3))
+
+
+def test_cg_matches_oracle_iterates():
+  from swirl_fem_amd.linalg.cg import cg
+  rng = np.random.default_rng(17)
+  n = 200
+  Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  Amat = Q @ np.diag(np.linspace(1, 50, n)) @ Q.T
+  b = rng.standard_normal(n)
+  Ad = dev(Amat)
+  for tol, maxiter in [(1e-5, None), (1e-12, None), (1e-12, 7)]:
+    xo, io = O.cg(lambda x: Amat @ x, b, tol=tol, maxiter=maxiter)
+    xg, ig = cg(lambda x: Ad @ x, dev(b), tol=tol, maxiter=maxiter,
+                check_every=5)
+    assert ig['num_iterations'] == io['num_iterations']
+    assert relerr(xg, xo) < 1e-9
+    assert float(ig['residual']) == pytest.approx(io['residual'], rel=1e-6)
+  # preconditioned: Jacobi
+  dinv = 1.0 / np.diag(Amat)
+  xo, io = O.cg(lambda x: Amat @ x, b, tol=1e-10, M=lambda r: dinv * r)
+  dd = dev(dinv)
+  xg, ig = cg(lambda x: Ad @ x, dev(b), tol=1e-10, M=lambda r: dd * r)
+  assert ig['num_iterations'] == io['num_iterations']
+  assert relerr(xg, xo) < 1e-9
+  # zero right-hand side: no iterations
+  xg, ig = cg(lambda x: Ad @ x, dev(np.zeros(n)))
+  assert ig['num_iterations'] == 0 and float(xg.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ Poisson
+def test_poisson_config1_matches_oracle_and_series():
+  """BASELINE config 1: 2D Poisson, 16x16 quads on [-1,1]^2, p=3."""
+  from swirl_fem_amd.examples.poisson import BCType, solve_poisson
+  P = 4
+  pm = unit_cube_mesh(16, ndim=2, a=-1.0, b=1.0)
+  rp = refine_premesh(pm, Nodes1D.create(P, NT['gll']))
+  mesh = rp.finalize(device=DEV)
+  assert mesh.num_nodes == 2401
+  f = np.ones(mesh.num_nodes)
+  u, info = solve_poisson(mesh, dev(f), {'boundary': (BCType.DIRICHLET, 0.)},
+                          rtol=1e-12, return_info=True)
+  bmask = mesh.physical_masks['boundary'].cpu().numpy()
+  uo, io = O.solve_poisson(rp.node_coords, rp.elements, (P, 'gll'), bmask, f,
+                           rtol=1e-12, return_ops=True)[:2]
+  assert relerr(u, uo) < 1e-9
+  assert abs(info['num_iterations'] - io['num_iterations']) <= 2
+  x = rp.node_coords
+  s = np.zeros(len(x))
+  for k in range(1, 40, 2):
+    s += (1 / (k ** 3 * np.sinh(k * np.pi))) * np.sin(
+        k * np.pi * (1 + x[:, 0]) / 2) * (
+            np.sinh(k * np.pi * (1 - x[:, 1]) / 2) +
+            np.sinh(k * np.pi * (1 + x[:, 1]) / 2))
+  exact = (1 - x[:, 0] ** 2) / 2 - (16 / np.pi ** 3) * s
+  assert np.abs(u.cpu().numpy() - exact).max() < 2e-5
+  # default tolerance path of the reference (rtol 1e-5)
+  u5 = solve_poisson(mesh, dev(f), {'boundary': (BCType.DIRICHLET, 0.)})
+  assert np.abs(u5.cpu().numpy() - exact).max() < 1e-4
+  with pytest.raises(NotImplementedError):
+    solve_poisson(mesh, dev(f), {'boundary': (BCType.DIRICHLET, 1.)})
+
+
+def test_poisson_reference_1d_and_circle():
+  from swirl_fem_amd.examples.poisson import BCType, solve_poisson
+  nn = 33
+  coords = np.linspace(0, 1, nn).reshape(nn, 1)
+  elements = np.array([[i, i + 1] for i in range(32)])
+  mesh = Premesh.create(coords, elements, physical_groups={
+      'boundary': np.array([[0, nn - 1]], np.int32)}).finalize(device=DEV)
+  bc = {'boundary': (BCType.DIRICHLET, 0.)}
+  u = solve_poisson(mesh, dev(np.ones(nn)), bc)
+  np.testing.assert_allclose(u.cpu().numpy(),
+                             .5 * (coords[:, 0] - coords[:, 0] ** 2),
+                             rtol=1e-6, atol=1e-12)
+  u = solve_poisson(mesh, dev(6 * coords[:, 0]), bc)
+  np.testing.assert_allclose(u.cpu().numpy(), coords[:, 0] - coords[:, 0] ** 3,
+                             rtol=1e-6, atol=1e-12)
+  pm = unit_cube_mesh(32, ndim=2, a=-1.0, b=1.0)
+  x = pm.node_coords
+  r2 = 1 / np.sqrt(2)
+  xc = np.stack([
+      x[:, 0] * (np.cos(np.pi * x[:, 1] / 4) - r2) + np.sin(np.pi * x[:, 0] / 4),
+      x[:, 1] * (np.cos(np.pi * x[:, 0] / 4) - r2) + np.sin(np.pi * x[:, 1] / 4)],
+                axis=-1)
+  mesh = pm.replace(node_coords=xc).finalize(device=DEV)
+  u = solve_poisson(mesh, dev(np.ones(mesh.num_nodes)), bc)
+  np.testing.assert_allclose(u.cpu().numpy(), .25 * (1 - (xc ** 2).sum(-1)),
+                             rtol=1e-6, atol=1e-4)
+
+
+# -------------------------------------------- full-size properties (config 2)
+@pytest.mark.parametrize('n', [int(os.environ.get('SFEM_TEST_FULL_N', '32'))])
+def test_config2_properties_full_size(n):
+  """3D p=7 Laplacian at bench scale: symmetry, nullspace, linearity,
+  fused == generic path, assembled == deterministic assembly."""
+  P = 8
+  rng = np.random.default_rng(18)
+  pm = unit_cube_mesh(n, ndim=3)
+  h = 1.0 / n
+  pm = pm.replace(node_coords=pm.node_coords + 0.2 * h *
+                  rng.uniform(-1, 1, pm.node_coords.shape))
+  grid = Nodes1D.create(P, NT['gll'])
+  mesh = refine_premesh(pm, grid).finalize(device=DEV)
+  fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
+  op = fes.helmholtz_operator(None)
+  g = torch.Generator(device=DEV).manual_seed(0)
+  u = torch.randn(mesh.num_nodes, dtype=torch.float64, device=DEV, generator=g)
+  v = torch.randn(mesh.num_nodes, dtype=torch.float64, device=DEV, generator=g)
+  Au, Av = op.apply(u), op.apply(v)
+  scale = float(Au.abs().max())
+  # symmetric
+  assert abs(float(torch.dot(Au, v) - torch.dot(u, Av))) < 1e-9 * abs(
+      float(torch.dot(Au, v)))
+  # constants in the nullspace, linearity
+  assert float(op.apply(torch.ones_like(u)).abs().max()) < 1e-10 * scale
+  lin = op.apply(2.0 * u - 3.0 * v) - (2.0 * Au - 3.0 * Av)
+  assert float(lin.abs().max()) < 1e-11 * scale
+  # fused kernel == generic (basis_eval / basis_eval_t) path == CSR assembly
+  uf = fes.scalar_function(mesh.gather(u))
+  loc = fes.local_covector(
+      lambda a, b: lambda x: torch.vdot(grad(a)(x), grad(b)(x)),
+      (uf, fes.scalar_function(None)))
+  gen = mesh.scatter(loc)
+  assert float((gen - Au).abs().max()) < 1e-10 * scale
+  from swirl_fem_amd import _ops
+  off, slots = mesh.assembly_plan().csr()
+  det = _ops.scatter_csr(loc, off, slots, mesh.num_nodes)
+  assert float((det - Au).abs().max()) < 1e-10 * scale
+  loc2 = op.apply_local(mesh.gather(u), 0.0, 1.0)
+  assert float((loc2 - loc).abs().max()) < 1e-10 * float(loc.abs().max())
