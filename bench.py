@@ -103,6 +103,11 @@ def main():
   ap.add_argument('--n', type=int, default=64, help='elements per dim per GPU')
   ap.add_argument('--p', type=int, default=7, help='polynomial order')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--stored-factors', action='store_true',
+                  help='read 6 geometric factors per point even on affine '
+                       'elements (the general-geometry kernel path)')
+  ap.add_argument('--jitter', type=float, default=0.0,
+                  help='smooth mesh deformation amplitude (fraction of h)')
   args = ap.parse_args()
 
   import torch
@@ -129,10 +134,11 @@ def main():
   t_setup = time.perf_counter()
   from swirl_fem_amd.distributed import blocks
   part = blocks.build_block_partition(args.n, P, block_grid(world), rank,
-                                      device=device)
+                                      device=device, jitter=args.jitter)
   mesh = part.mesh
   fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
-  op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'))
+  op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
+                              exploit_affine=not args.stored_factors)
   setup_s = time.perf_counter() - t_setup
 
   N_local = mesh.num_nodes
@@ -192,8 +198,7 @@ def main():
     if hi > lo:
       out_buf[lo:hi].zero_()                 # outside the event pair
     s0.record()
-    _ops.helmholtz_apply(u, out_buf, op.enc, op.geo, op.dmat, 3, P, 0.0, 1.0,
-                         (0, 0))
+    op.apply(u, 0.0, 1.0, out=out_buf, zero=False)
     s1.record()
   torch.cuda.synchronize()
   kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
@@ -225,12 +230,18 @@ def main():
             'blocks': 'x'.join(map(str, block_grid(world))),
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
             'apply_ms': apply_ms, 'setup_s': setup_s,
+            'geometry': ('%d of %d elements affine: 7 constants per element, '
+                         'quadrature weights applied in-kernel; the rest read '
+                         '6 stored factors per point' % (op.num_affine, E)),
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
             'kernel': 'sfem::helmholtz_kernel<double, 8, 3, true, true>',
             'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg_bytes,
+            'note': ('algorithmic bytes are the stored-6-factor model of '
+                     'SURVEY 8(d) for every element; affine elements move '
+                     'fewer bytes than the model (no per-point factors)'),
         },
     }
     if world == 1 and not args.no_cpu_baseline:

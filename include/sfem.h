@@ -151,15 +151,31 @@ int sfem_basis_eval_t(const void* c0, const void* c1, const void* interp1,
  * i.e. the mass form u.v, the stiffness form grad u : grad v and their
  * combination H = (beta_k/dt) B + mu A in one pass over the elements:
  * examples/poisson.py:141-154, navier_stokes.py:220-236, :295-307, :431.
- * Setup builds, per quadrature point, the symmetric factors
- *     geo[0..ng) = w detJ (J^-1 J^-T)  (ng = 3 in 2D, 6 in 3D: 00,01,(02),11,(12),(22))
- *     geo[ng]    = w detJ
- * laid out (E, ng+1, Q) (sfem_helmholtz_setup), and the encoded indices
- * (sfem_encode_elements).                                                    */
+ *
+ * Operator data (built once, opaque to the caller):
+ *   geo       per-point symmetric factors w detJ (J^-1 J^-T) (3 in 2D, 6 in 3D)
+ *             plus w detJ, ndim(ndim+1)/2 + 1 reals per point, for the elements
+ *             listed in geo_index (all elements when geo_index is NULL);
+ *             written by sfem_helmholtz_setup.
+ *   geo_elem  (E, 8) per-element constants detJ (J^-1 J^-T), detJ for AFFINE
+ *             elements (constant Jacobian): their per-point factors are that
+ *             constant times the tensor quadrature weight, so the kernel never
+ *             reads per-point data for them; written by
+ *             sfem_helmholtz_setup_affine.  NULL if geo_index is NULL.
+ *   geo_index (E,) int32: slot of the element in `geo`, or -1 = affine.
+ *   enc       encoded indices (sfem_encode_elements).
+ * Three geometry modes are selected by which pointers are non-NULL:
+ *   geo only                      every element reads per-point factors
+ *   geo_elem only (+ weights)     every element is affine
+ *   geo, geo_elem, geo_index      mixed, decided per element                  */
 int sfem_helmholtz_setup(const void* invjac, const void* jacdet,
                          const void* weights_nd /* (Q,) */, void* geo,
                          int64_t num_elements, int ndim, int Q, int dtype,
                          sfem_stream_t stream);
+int sfem_helmholtz_setup_affine(const void* invjac, const void* jacdet,
+                                void* geo_elem /* (E, 8) */,
+                                int64_t num_elements, int ndim, int Q,
+                                int dtype, sfem_stream_t stream);
 
 /* enc[i] = node id | flags.  dirichlet (num_nodes,) uint8 or NULL,
  * multiplicity (num_nodes,) int32 = number of slots referencing each node.   */
@@ -171,9 +187,13 @@ typedef struct sfem_helmholtz_args {
   const void* u;          /* (N, ncomp)                                       */
   void* out;              /* (N, ncomp); every entry is written by the call   */
   const int32_t* enc;     /* (E, n) encoded indices                           */
-  const void* geo;        /* (E, ng+1, Q)                                     */
+  const void* geo;        /* per-point factors (see above)                    */
+  const void* geo_elem;   /* (E, 8) or NULL                                   */
+  const int32_t* geo_index; /* (E,) or NULL                                   */
   const void* dmat;       /* HOST pointer: (P, P) 1D differentiation matrix,  */
                           /*   row-major, of `dtype`                          */
+  const void* weights;    /* HOST pointer: (P,) 1D quadrature weights of      */
+                          /*   `dtype` (needed with geo_index), or NULL       */
   int64_t num_elements;
   int64_t num_nodes;
   int64_t zero_begin;     /* out[zero_begin:zero_end) is cleared first: must  */
@@ -190,11 +210,13 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* args, sfem_stream_t stream);
 
 /* Element-local variant (no gather/scatter): out_local (E, n, ncomp).
  * StokesVelocity.A_local / B_local (navier_stokes.py:220-236).
- * `dmat` is a HOST pointer as in sfem_helmholtz_args.                        */
+ * `dmat` and `weights` are HOST pointers as in sfem_helmholtz_args.          */
 int sfem_helmholtz_local(const void* u_local, void* out_local, const void* geo,
-                         const void* dmat, int64_t num_elements, int ndim,
-                         int P, int ncomp, double lambda0, double lambda1,
-                         int dtype, sfem_stream_t stream);
+                         const void* geo_elem, const int32_t* geo_index,
+                         const void* dmat, const void* weights,
+                         int64_t num_elements, int ndim, int P, int ncomp,
+                         double lambda0, double lambda1, int dtype,
+                         sfem_stream_t stream);
 
 /* ------------------------------------------------------------ CG kernels ---
  * Preconditioned CG of linalg/cg.py:30-97 with device-resident scalars: no

@@ -238,16 +238,37 @@ def encode_elements(elements, dirichlet_u8, multiplicity):
   return enc
 
 
+def helmholtz_setup_affine(invjac, jacdet):
+  dev = _dev(invjac, jacdet)
+  E, Q, ndim, _ = invjac.shape
+  geo_elem = torch.empty((E, 8), dtype=invjac.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_helmholtz_setup_affine(
+        _ptr(invjac), _ptr(jacdet), _ptr(geo_elem), E, ndim, Q,
+        _dtype_code(invjac), _stream(dev)), 'sfem_helmholtz_setup_affine')
+  return geo_elem
+
+
+def _host(a, dtype):
+  np_dt = np.float64 if dtype == torch.float64 else np.float32
+  return None if a is None else np.ascontiguousarray(a, dtype=np_dt)
+
+
 def helmholtz_apply(u, out, enc, geo, dmat_host: np.ndarray, ndim, P,
-                    lambda0, lambda1, zero_range):
+                    lambda0, lambda1, zero_range, geo_elem=None,
+                    geo_index=None, weights_host=None):
   """out <- mask * scatter((l0 B + l1 A)_local(gather(u))); returns out."""
-  dev = _dev(u, out, enc, geo)
+  dev = _dev(u, out, enc, geo, geo_elem, geo_index)
   ncomp = 1 if u.dim() == 1 else u.shape[-1]
-  np_dt = np.float64 if u.dtype == torch.float64 else np.float32
-  dmat_host = np.ascontiguousarray(dmat_host, dtype=np_dt)
+  dmat_host = _host(dmat_host, u.dtype)
+  weights_host = _host(weights_host, u.dtype)
   args = _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=enc.data_ptr(),
-      geo=geo.data_ptr(), dmat=dmat_host.ctypes.data,
+      geo=None if geo is None else geo.data_ptr(),
+      geo_elem=None if geo_elem is None else geo_elem.data_ptr(),
+      geo_index=None if geo_index is None else geo_index.data_ptr(),
+      dmat=dmat_host.ctypes.data,
+      weights=None if weights_host is None else weights_host.ctypes.data,
       num_elements=enc.shape[0], num_nodes=u.shape[0],
       zero_begin=int(zero_range[0]), zero_end=int(zero_range[1]), ndim=ndim,
       P=P, ncomp=ncomp, dtype=_dtype_code(u), lambda0=float(lambda0),
@@ -260,19 +281,21 @@ def helmholtz_apply(u, out, enc, geo, dmat_host: np.ndarray, ndim, P,
 
 
 def helmholtz_local(u_local, geo, dmat_host: np.ndarray, ndim, P, lambda0,
-                    lambda1):
+                    lambda1, geo_elem=None, geo_index=None, weights_host=None):
   u_local = u_local.contiguous()
-  dev = _dev(u_local, geo)
+  dev = _dev(u_local, geo, geo_elem, geo_index)
   ncomp = 1 if u_local.dim() == 2 else u_local.shape[-1]
-  np_dt = np.float64 if u_local.dtype == torch.float64 else np.float32
-  dmat_host = np.ascontiguousarray(dmat_host, dtype=np_dt)
+  dmat_host = _host(dmat_host, u_local.dtype)
+  weights_host = _host(weights_host, u_local.dtype)
   out = torch.empty_like(u_local)
   with torch.cuda.device(dev):
     _lib.check(_lib.load().sfem_helmholtz_local(
-        _ptr(u_local), _ptr(out), _ptr(geo),
-        ctypes.c_void_p(dmat_host.ctypes.data), u_local.shape[0], ndim, P,
-        ncomp, float(lambda0), float(lambda1), _dtype_code(u_local),
-        _stream(dev)), 'sfem_helmholtz_local')
+        _ptr(u_local), _ptr(out), _ptr(geo), _ptr(geo_elem), _ptr(geo_index),
+        ctypes.c_void_p(dmat_host.ctypes.data),
+        None if weights_host is None else ctypes.c_void_p(
+            weights_host.ctypes.data),
+        u_local.shape[0], ndim, P, ncomp, float(lambda0), float(lambda1),
+        _dtype_code(u_local), _stream(dev)), 'sfem_helmholtz_local')
   return out
 
 

@@ -153,15 +153,48 @@ __device__ inline double block_sum(double v) {
   return total;  // valid on thread 0
 }
 
+// Streaming vector kernels move 16 bytes per lane per access (dwordx4: the
+// widest, 1 KiB per wave-instruction) with 4 independent accesses in flight per
+// lane; the last < VEC elements are handled by a scalar tail.
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<double> {
+  using type = double2;
+  static constexpr int N = 2;
+};
+template <>
+struct Vec16<float> {
+  using type = float4;
+  static constexpr int N = 4;
+};
+
+template <typename T>
+__device__ __forceinline__ T vget(const typename Vec16<T>::type& v, int i) {
+  return reinterpret_cast<const T*>(&v)[i];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(512)
 dot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t count,
            double* __restrict__ result) {
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const int64_t nvec = count / VN;
+  const V* av = reinterpret_cast<const V*>(a);
+  const V* bv = reinterpret_cast<const V*>(b);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-       i += stride)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    const V x = av[i], y = bv[i];
+#pragma unroll
+    for (int c = 0; c < VN; ++c) acc += (double)vget<T>(x, c) * (double)vget<T>(y, c);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
     acc += (double)a[i] * (double)b[i];
+  }
   const double total = block_sum(acc);
   if (threadIdx.x == 0) unsafeAtomicAdd(result, total);
 }
@@ -174,12 +207,33 @@ cg_update_xr_kernel(T* __restrict__ x, T* __restrict__ r,
                     const T* __restrict__ p, const T* __restrict__ ap,
                     int64_t count, double* __restrict__ scalars) {
   if (scalars[7] != 0.0) return;  // converged: iteration is a no-op
-  const double alpha_d = scalars[0] / scalars[1];
-  const T alpha = (T)alpha_d;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const T alpha = (T)(scalars[0] / scalars[1]);
+  const int64_t nvec = count / VN;
+  V* xv = reinterpret_cast<V*>(x);
+  V* rv = reinterpret_cast<V*>(r);
+  const V* pv = reinterpret_cast<const V*>(p);
+  const V* apv = reinterpret_cast<const V*>(ap);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += stride) {
+    V xx = xv[i], rr = rv[i];
+    const V pp = pv[i], aa = apv[i];
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* xe = reinterpret_cast<T*>(&xx) + c;
+      T* re = reinterpret_cast<T*>(&rr) + c;
+      *xe += alpha * vget<T>(pp, c);
+      *re -= alpha * vget<T>(aa, c);
+      if (FUSE_RR) acc += (double)*re * (double)*re;
+    }
+    xv[i] = xx;
+    rv[i] = rr;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
     x[i] += alpha * p[i];
     const T rn = r[i] - alpha * ap[i];
     r[i] = rn;
@@ -196,11 +250,28 @@ __global__ void __launch_bounds__(512)
 cg_update_p_kernel(T* __restrict__ p, const T* __restrict__ z, int64_t count,
                    const double* __restrict__ scalars) {
   if (scalars[7] != 0.0) return;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
   const T beta = (T)(scalars[2] / scalars[0]);
+  const int64_t nvec = count / VN;
+  V* pv = reinterpret_cast<V*>(p);
+  const V* zv = reinterpret_cast<const V*>(z);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-       i += stride)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    V pp = pv[i];
+    const V zz = zv[i];
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* pe = reinterpret_cast<T*>(&pp) + c;
+      *pe = vget<T>(zz, c) + beta * *pe;
+    }
+    pv[i] = pp;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
     p[i] = z[i] + beta * p[i];
+  }
 }
 
 // One-thread bookkeeping between the vector kernels of an iteration.
@@ -239,10 +310,29 @@ template <typename T>
 __global__ void __launch_bounds__(512)
 axpby_kernel(T a, const T* __restrict__ x, T b, T* __restrict__ y,
              int64_t count) {
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const int64_t nvec = count / VN;
+  const V* xv = reinterpret_cast<const V*>(x);
+  V* yv = reinterpret_cast<V*>(y);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-       i += stride)
-    y[i] = a * x[i] + (b == T(0) ? T(0) : b * y[i]);
+  const bool use_y = b != T(0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    const V xx = xv[i];
+    V yy;
+    if (use_y) yy = yv[i];
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* ye = reinterpret_cast<T*>(&yy) + c;
+      *ye = a * vget<T>(xx, c) + (use_y ? b * *ye : T(0));
+    }
+    yv[i] = yy;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
+    y[i] = a * x[i] + (use_y ? b * y[i] : T(0));
+  }
 }
 
 }  // namespace sfem

@@ -44,11 +44,15 @@ struct HelmholtzParams {
   const T* u;            // (N, nc) or (E, n, nc) when !GS
   T* out;
   const int32_t* enc;    // (E, n) encoded indices (GS only)
-  const T* geo;          // (E, ng + 1, Q)
+  const T* geo;          // per-point factors of the non-affine elements
+  const T* geo_elem;     // (E, 8) per-element constants, or null
+  const int32_t* geo_index;  // (E,) slot in `geo`, -1 = affine; or null
   const T* dmat_host;    // (P, P) on the HOST; travels as a kernel argument
+  const T* weights_host; // (P,) quadrature weights on the HOST (affine path)
   int64_t num_elements;
   int ncomp;
   T lambda0, lambda1;
+  int debug_flags;       // reserved for A/B experiments (SFEM_DEBUG_FLAGS)
 };
 
 __host__ __device__ constexpr int round_up(int a, int b) {
@@ -103,12 +107,14 @@ struct DMat {
   static constexpr int PH = P / 2, PC = P - P / 2;
   T e[PH * PC];   // E[r][m], r < PH, m < PC
   T o[PC * PH];   // O[r][m], r < PC, m < PH
+  T w[P];         // 1D quadrature weights (affine elements)
 };
 
 template <typename T, int P>
-inline DMat<T, P> make_dmat(const T* d) {
+inline DMat<T, P> make_dmat(const T* d, const T* w) {
   constexpr int PH = P / 2, PC = P - P / 2;
   DMat<T, P> dm;
+  for (int r = 0; r < P; ++r) dm.w[r] = w ? w[r] : T(0);
   for (int r = 0; r < PH; ++r)
     for (int m = 0; m < PC; ++m)
       dm.e[r * PC + m] = m < PH ? (d[r * P + m] + d[r * P + P - 1 - m]) / 2
@@ -163,7 +169,9 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nblocks) {
   return start + k;
 }
 
-template <typename T, int P, int DIM, bool GS, bool SCALAR>
+// GM (geometry mode): 0 = every element reads per-point factors, 1 = every
+// element is affine, 2 = mixed (per element, via geo_index).
+template <typename T, int P, int DIM, bool GS, bool SCALAR, int GM>
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
@@ -178,7 +186,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   const int t = tid - el * TPE;             // lane within the element
   const int i = DIM == 3 ? t / P : 0;
   const int j = DIM == 3 ? t - i * P : t;
-  const int64_t e0 = xcd_remap(blockIdx.x, gridDim.x) * EPB;   // wave-uniform
+  const int64_t e0 = (int64_t)blockIdx.x * EPB;   // wave-uniform
   const bool lane_ok = el < EPB;            // tail lanes of a padded block
   const bool active = lane_ok && e0 + el < prm.num_elements;
 
@@ -194,13 +202,54 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   // Owner layout: this lane holds nodes (a, i, j), a = 0..P-1, i.e. element
   // slots a*TPE + t.  All per-element arrays are addressed as a wave-uniform
   // base (SGPR pair) + one 32-bit per-lane byte offset + compile-time constant.
-  const char* geo0 =
-      reinterpret_cast<const char*>(prm.geo + e0 * (int64_t)(NG + 1) * N);
-  const uint32_t geo_off = (uint32_t)((el * (NG + 1) * N + t) * sizeof(T));
-  const uint32_t slot_off = (uint32_t)(el * N + t);
-  auto geo_at = [&](int f, int a) -> T {
-    // uniform (SGPR) base per factor + shared lane offset + small immediate
-    const char* base = geo0 + (size_t)f * N * sizeof(T);
+  // Affine elements (constant Jacobian) keep 7 numbers per ELEMENT instead of
+  // per point: G(q) = w_q * (detJ J^-1 J^-T), W(q) = w_q detJ with w_q the
+  // tensor quadrature weight.  `geo_index` maps the other elements to their
+  // slot in the per-point array.
+  const int64_t e_lane = e0 + (lane_ok ? el : 0);
+  int64_t gslot = e_lane;
+  if (GM == 2) gslot = active ? prm.geo_index[e_lane] : 0;
+  const bool affine = GM == 1 || (GM == 2 && gslot < 0);
+  T cg[GM == 0 ? 1 : 7];
+  T wbc = T(0);
+  if (GM != 0 && affine) {
+    const T* ce = prm.geo_elem + e_lane * 8;
+#pragma unroll
+    for (int f = 0; f < 7; ++f) cg[f] = ce[f];
+    // per-lane lookup by select chain (a runtime index into a by-value kernel
+    // argument would force the struct into scratch)
+    T wi = T(0), wj = T(0);
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      wi = i == r ? dm.w[r] : wi;
+      wj = j == r ? dm.w[r] : wj;
+    }
+    wbc = DIM == 3 ? wi * wj : wj;
+  }
+  const char* geo0 = reinterpret_cast<const char*>(
+      prm.geo + (GM == 1 || affine ? 0 : gslot) * (int64_t)(NG + 1) * N);
+  uint32_t geo_off_v = (uint32_t)(t * sizeof(T));
+  uint32_t slot_off_v = (uint32_t)(el * N + t);
+  const uint32_t& geo_off = geo_off_v;
+  const uint32_t& slot_off = slot_off_v;
+  // Geometric factors are stored in pairs so that fp64 reads are 16 bytes per
+  // lane (1 KiB per wave-instruction):
+  //   3D: [pair 0..2][Q][2] = (G00,G01) (G02,G11) (G12,G22), then W [Q]
+  //   2D: [pair 0..1][Q][2] = (G00,G01) (G11,W)
+  // Each access is a wave-uniform (SGPR) base + one shared lane offset + a
+  // small immediate.
+  typedef T Pair __attribute__((ext_vector_type(2)));
+  auto geo_pair = [&](int pi, int a) -> Pair {
+    const char* base = geo0 + (size_t)pi * 2 * N * sizeof(T);
+    const Pair* ptr = reinterpret_cast<const Pair*>(
+        base + (2 * geo_off + (uint32_t)(2 * a * TPE * sizeof(T))));
+    // streamed once: non-temporal so the factors do not evict the gathered
+    // nodal values that neighbouring elements re-read from L2 / MALL
+    return *ptr;
+  };
+  auto geo_mass = [&](int a) -> T {
+    if (DIM == 2) return geo_pair(1, a).y;
+    const char* base = geo0 + (size_t)6 * N * sizeof(T);
     return *reinterpret_cast<const T*>(
         base + (geo_off + (uint32_t)(a * TPE * sizeof(T))));
   };
@@ -217,6 +266,12 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   T* ol0 = GS ? nullptr : prm.out + e0 * N * nc;
 
   for (int k = 0; k < nc; ++k) {
+    if (!SCALAR) {
+      // keep address arithmetic and flag tests inside the component loop:
+      // hoisted out of it they occupy ~100 registers and spill
+      asm volatile("" : "+v"(geo_off_v), "+v"(slot_off_v));
+      if (GM != 0) asm volatile("" : "+v"(wbc));
+    }
     T ua[P], acc[P];
 #pragma unroll
     for (int a = 0; a < P; ++a) {
@@ -267,14 +322,31 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
           const int o = a * SA + i * SB + j;
           if (DIM == 3) {
             const T g0 = d0[a], g1 = s0[o], g2 = s1[o];
-            const T G00 = geo_at(0, a), G01 = geo_at(1, a), G02 = geo_at(2, a),
-                    G11 = geo_at(3, a), G12 = geo_at(4, a), G22 = geo_at(5, a);
+            T G00 = T(0), G01 = T(0), G02 = T(0), G11 = T(0), G12 = T(0),
+              G22 = T(0);
+            if (GM != 0 && affine) {
+              const T sc = wbc * dm.w[a];
+              G00 = cg[0] * sc; G01 = cg[1] * sc; G02 = cg[2] * sc;
+              G11 = cg[3] * sc; G12 = cg[4] * sc; G22 = cg[5] * sc;
+            } else if (GM != 1) {
+              const Pair p0 = geo_pair(0, a), p1 = geo_pair(1, a),
+                         p2 = geo_pair(2, a);
+              G00 = p0.x; G01 = p0.y; G02 = p1.x; G11 = p1.y;
+              G12 = p2.x; G22 = p2.y;
+            }
             w0[a] = G00 * g0 + G01 * g1 + G02 * g2;
             s0[o] = G01 * g0 + G11 * g1 + G12 * g2;
             s1[o] = G02 * g0 + G12 * g1 + G22 * g2;
           } else {
             const T g0 = d0[a], g1 = s0[o];
-            const T G00 = geo_at(0, a), G01 = geo_at(1, a), G11 = geo_at(2, a);
+            T G00 = T(0), G01 = T(0), G11 = T(0);
+            if (GM != 0 && affine) {
+              const T sc = wbc * dm.w[a];
+              G00 = cg[0] * sc; G01 = cg[1] * sc; G11 = cg[2] * sc;
+            } else if (GM != 1) {
+              const Pair p0 = geo_pair(0, a), p1 = geo_pair(1, a);
+              G00 = p0.x; G01 = p0.y; G11 = p1.x;
+            }
             w0[a] = G00 * g0 + G01 * g1;
             s0[o] = G01 * g0 + G11 * g1;
           }
@@ -317,7 +389,10 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
     if (has_mass && active) {
 #pragma unroll
       for (int a = 0; a < P; ++a)
-        acc[a] += prm.lambda0 * geo_at(NG, a) * ua[a];
+        acc[a] += prm.lambda0 *
+                  ((GM != 0 && affine) ? cg[GM == 0 ? 0 : 6] * wbc * dm.w[a]
+                                       : (GM != 1 ? geo_mass(a) : T(0))) *
+                  ua[a];
     }
     // direct-stiffness summation
 #pragma unroll
@@ -353,15 +428,22 @@ int launch_helmholtz(const HelmholtzParams<T>& prm, hipStream_t stream) {
     set_error("helmholtz: too many workgroups (%lld)", (long long)groups);
     return SFEM_EINVAL;
   }
-  const DMat<T, P> dm = make_dmat<T, P>(prm.dmat_host);
-  if (prm.ncomp == 1)
-    hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, true>),
-                       dim3((unsigned)groups), dim3(Tile::BLOCK), 0, stream,
-                       prm, dm);
-  else
-    hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, false>),
-                       dim3((unsigned)groups), dim3(Tile::BLOCK), 0, stream,
-                       prm, dm);
+  const DMat<T, P> dm = make_dmat<T, P>(prm.dmat_host, prm.weights_host);
+  const dim3 grid((unsigned)groups), block(Tile::BLOCK);
+  const int gm = prm.geo_elem == nullptr ? 0 : (prm.geo == nullptr ? 1 : 2);
+#define SFEM_LAUNCH_GM(SC, GMV)                                              \
+  hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, SC, GMV>), grid, block, \
+                     0, stream, prm, dm)
+  if (prm.ncomp == 1) {
+    if (gm == 0) SFEM_LAUNCH_GM(true, 0);
+    else if (gm == 1) SFEM_LAUNCH_GM(true, 1);
+    else SFEM_LAUNCH_GM(true, 2);
+  } else {
+    if (gm == 0) SFEM_LAUNCH_GM(false, 0);
+    else if (gm == 1) SFEM_LAUNCH_GM(false, 1);
+    else SFEM_LAUNCH_GM(false, 2);
+  }
+#undef SFEM_LAUNCH_GM
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

@@ -375,6 +375,44 @@ def test_fused_helmholtz_fp32_and_vector(ndim, n, P):
     assert relerr(got, ofes.stiffness_local(ul)) < tol
 
 
+@pytest.mark.parametrize('ndim,n,P', [(2, 4, 5), (3, 3, 4), (3, 3, 8)])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_fused_helmholtz_affine_elements(ndim, n, P, dtype):
+  """Affine elements use 7 constants per element; mixed meshes use both."""
+  rng = np.random.default_rng(19)
+  tol = 1e-10 if dtype == torch.float64 else 2e-5
+  for mode in ('structured', 'sheared', 'mixed'):
+    pm = unit_cube_mesh(n, ndim=ndim)
+    x = pm.node_coords.copy()
+    if mode == 'sheared':       # affine map of the whole mesh: still affine
+      A = np.eye(ndim) + 0.3 * rng.uniform(-1, 1, (ndim, ndim))
+      x = x @ A.T + 0.1
+    if mode == 'mixed':         # move one interior vertex: 2^d elements bend
+      centre = np.argmin(((x - 0.5) ** 2).sum(-1))
+      x[centre] += 0.1 / n
+    rp = refine_premesh(pm.replace(node_coords=x),
+                        Nodes1D.create(P, NT['gll']))
+    mesh, fes, ofes = spaces(rp, P, P, 'gll', dtype)
+    bmask = mesh.physical_masks['boundary'].cpu().numpy()
+    op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
+    op_pp = fes.helmholtz_operator(mesh.physical_masks['boundary'],
+                                   exploit_affine=False)
+    if mode == 'mixed':
+      assert 0 < op.num_affine < mesh.num_elements
+    elif dtype == torch.float64:
+      assert op.num_affine == mesh.num_elements
+    assert op_pp.num_affine == 0
+    for nc in (1, ndim):
+      u = rng.standard_normal((mesh.num_nodes, nc))
+      uu = u[:, 0] if nc == 1 else u
+      ref = _helmholtz_ref(ofes, uu, 0.4, 1.1, bmask)
+      assert relerr(op.apply(dev(uu, dtype), 0.4, 1.1), ref) < tol, mode
+      assert relerr(op_pp.apply(dev(uu, dtype), 0.4, 1.1), ref) < tol, mode
+    ul = rng.standard_normal(rp.elements.shape)
+    ref = 0.2 * ofes.mass_local(ul) + ofes.stiffness_local(ul)
+    assert relerr(op.apply_local(dev(ul, dtype), 0.2, 1.0), ref) < tol, mode
+
+
 def test_fused_helmholtz_padded_elements_and_errors():
   # partition-style padding: trailing elements with all -1 connectivity
   rp = make_case(3, 2, 4, seed=15)

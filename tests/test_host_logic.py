@@ -1,0 +1,395 @@
+"""CPU tests of the host-side logic (no GPU, no HIP compute calls).
+
+Covers: 1D matrices, mesh staging, refiner and index builders against the
+reference goldens; facet tables; the quadrature-expression algebra behind
+`local_covector`; the C-ABI library (loads, exports every declared symbol);
+the partition plans; error behaviour mirrored from the reference.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sfem_oracle as O
+from swirl_fem_amd.common import facet_util
+from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+from swirl_fem_amd.core import gather_scatter as GS
+from swirl_fem_amd.core import interpolation as I
+from swirl_fem_amd.core import qexpr
+from swirl_fem_amd.core.mesh import Mesh
+from swirl_fem_amd.core.mesh_refiner import refine_premesh
+from swirl_fem_amd.core.premesh import Premesh
+from swirl_fem_amd.core.qexpr import QExpr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NT = {'nc': I.NodeType.NEWTON_COTES, 'gl': I.NodeType.GAUSS_LEGENDRE,
+      'gll': I.NodeType.GAUSS_LOBATTO_LEGENDRE}
+
+
+# ------------------------------------------------------------ interpolation
+def test_interpolation_matches_reference_goldens(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'interp1d.npz'))
+  checked = 0
+  for key in g.files:
+    m = re.match(r'(nc|gl|gll)(\d+)_(nodes|weights|bary|D)$', key)
+    if m:
+      nodes = I.Nodes1D.create(int(m.group(2)), NT[m.group(1)])
+      bi = I.BarycentricInterpolator(1, nodes, nodes)
+      mine = {'nodes': nodes.node_values,
+              'weights': I.Quadrature1D.create_from_nodes_1d(nodes).weights,
+              'bary': bi._barycentric_weights(),
+              'D': bi._differentiation_matrix_1d()}[m.group(3)]
+      np.testing.assert_array_equal(mine, g[key], err_msg=key)
+      checked += 1
+    m = re.match(r'I_(nc|gl|gll)(\d+)_(nc|gl|gll)(\d+)$', key)
+    if m:
+      bi = I.BarycentricInterpolator(
+          1, I.Nodes1D.create(int(m.group(2)), NT[m.group(1)]),
+          I.Nodes1D.create(int(m.group(4)), NT[m.group(3)]))
+      np.testing.assert_array_equal(bi._interpolation_matrix_1d(), g[key], key)
+      checked += 1
+  assert checked > 200
+  for (d, gp, ep) in [(2, 3, 4), (3, 3, 3), (3, 2, 3)]:
+    bi = I.BarycentricInterpolator(d, I.Nodes1D.create(gp, NT['gll']),
+                                   I.Nodes1D.create(ep, NT['gl']))
+    np.testing.assert_array_equal(bi.interpolation_matrix(),
+                                  g[f'kron_M_d{d}_gll{gp}_gl{ep}'])
+    np.testing.assert_array_equal(bi.interpolation_matrix_grad(),
+                                  g[f'kron_G_d{d}_gll{gp}_gl{ep}'])
+  np.testing.assert_array_equal(
+      I.Quadrature1D.create(4, NT['gll']).weights_nd(3),
+      g['weights_nd_gll4_d3'])
+
+
+def test_interpolation_reference_known_answers():
+  # core/interpolation_test.py:39-59 (node values), :76-138 (exactness)
+  gll = I.Nodes1D.create(5, NT['gll']).node_values
+  np.testing.assert_allclose(gll, [-1, -np.sqrt(21) / 7, 0, np.sqrt(21) / 7, 1],
+                             atol=1e-14)
+  for nt, exact_deg in [('gl', lambda n: 2 * n - 1), ('gll', lambda n: 2 * n - 3)]:
+    for n in range(2, 9):
+      q = I.Quadrature1D.create(n, NT[nt])
+      for k in range(exact_deg(n) + 1):
+        assert np.dot(q.weights, q.nodes.node_values ** k) == pytest.approx(
+            (1 - (-1) ** (k + 1)) / (k + 1), abs=1e-13)
+  # differentiation of polynomials is exact; GLL p=7 corner entry
+  n8 = I.Nodes1D.create(8, NT['gll'])
+  D = I.BarycentricInterpolator(1, n8, n8)._differentiation_matrix_1d()
+  assert D[0, 0] == pytest.approx(-7 * 8 / 4)
+  x = n8.node_values
+  np.testing.assert_allclose(D @ x ** 5, 5 * x ** 4, atol=1e-12)
+  assert I.Nodes1D.create(3, NT['gll']) == I.Nodes1D.create(3, NT['gll'])
+  assert I.Nodes1D.create(3, NT['gll']) != I.Nodes1D.create(3, NT['gl'])
+  assert I.Nodes1D.create(3, NT['gll']).is_continuous()
+  assert not I.Nodes1D.create(3, NT['gl']).is_continuous()
+  with pytest.raises(ValueError):
+    I.Nodes1D.create(3, I.NodeType.SINGLE)
+
+
+def test_facet_tables_match_reference(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'facet_util.npz'))
+  for d, npts in [(1, 3), (2, 3), (2, 4), (1, 6)]:
+    mp = facet_util.get_orderings_mapping(d, npts)
+    keys = g[f'ord_d{d}_n{npts}_keys']
+    vals = g[f'ord_d{d}_n{npts}_vals']
+    assert len(mp) == len(keys) == 2 ** d * int(np.prod(range(1, d + 1)))
+    for k, v in zip(keys, vals):
+      np.testing.assert_array_equal(mp[tuple(k.tolist())], v)
+  assert len(facet_util.get_facet_types(3)) == 27
+  assert len(facet_util.get_facet_types(3, facet_ndim=2)) == 6
+  assert len(facet_util.get_facet_types(2, facet_ndim=0)) == 4
+
+
+# ------------------------------------------------------------- mesh staging
+def _golden_cases(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'meshes.npz'))
+  return g, sorted({k.split('/')[0] for k in g.files})
+
+
+def _get(g, prefix):
+  return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def _cmp(mine, ref, tag):
+  for k, v in ref.items():
+    m = mine['physical_groups'][k[6:]] if k.startswith('group_') else mine[k]
+    assert m.shape == v.shape, (tag, k, m.shape, v.shape)
+    if v.dtype.kind == 'f':
+      np.testing.assert_allclose(m, v, rtol=0, atol=1e-14, err_msg=f'{tag}/{k}')
+    else:
+      np.testing.assert_array_equal(m, v, err_msg=f'{tag}/{k}')
+
+
+def _pmd(pm):
+  return dict(node_coords=pm.node_coords, elements=pm.elements,
+              physical_groups=pm.physical_groups,
+              periodic_links=pm.periodic_links, partitions=pm.partitions)
+
+
+def test_mesh_staging_matches_reference_goldens(golden_dir):
+  """unit_cube_mesh, refine_premesh (incl. rotated elements, periodic links,
+  GL nodes) and the finalize index builders reproduce the reference exactly."""
+  g, names = _golden_cases(golden_dir)
+  assert len(names) >= 20
+  for name in names:
+    cube, scr = _get(g, name + '/cube/'), _get(g, name + '/scrambled/')
+    ref, fin = _get(g, name + '/refined/'), _get(g, name + '/final/')
+    ndim = cube['node_coords'].shape[1]
+    n = round(len(cube['node_coords']) ** (1 / ndim)) - 1
+    a, b = cube['node_coords'].min(), cube['node_coords'].max()
+    m = re.search(r'per(\d+)', name)
+    per = tuple(int(c) for c in m.group(1)) if m else ()
+    m = re.search(r'part(\d+)', name)
+    parts = None
+    if m:
+      shp = tuple(int(c) for c in m.group(1))
+      parts = np.arange(int(np.prod(shp))).reshape(shp)
+    pm = unit_cube_mesh(n, ndim=ndim, a=a, b=b, periodic_dims=per,
+                        partitions=parts)
+    if 'uneven' in name:
+      pm = pm.replace(partitions=cube['partitions'])
+    _cmp(_pmd(pm), cube, name + '/cube')
+    if scr:
+      pm = pm.replace(elements=scr['elements'])
+    P = round(ref['elements'].shape[1] ** (1 / ndim))
+    nt = 'gl' if re.search(r'_gl\d', name) else 'gll'
+    rp = refine_premesh(pm, I.Nodes1D.create(P, NT[nt]))
+    _cmp(_pmd(rp), ref, name + '/refined')
+    arrs = rp.finalize_all('i')
+    mine = dict(arrs, gather_indices=arrs['exchange_gather_indices'],
+                unique_indices=arrs['exchange_unique_indices'])
+    if 'global_node_ids' in arrs:
+      mine['local_nodes'] = arrs['global_node_ids']
+      mine['local_elements'] = arrs['elements']
+    _cmp(mine, fin, name + '/final')
+
+
+def test_unit_cube_mesh_counts():
+  # common/premesh_commons_test.py:26-48
+  for ndim in (1, 2, 3):
+    pm = unit_cube_mesh(4, ndim=ndim)
+    assert pm.num_nodes == 5 ** ndim and pm.num_elements == 4 ** ndim
+    assert pm.order == 1 and pm.elements.dtype == np.int32
+    assert len(pm.physical_groups['boundary']) == 2 * ndim * 4 ** (ndim - 1)
+  pm = unit_cube_mesh(4, ndim=2, periodic_dims=(0, 1))
+  assert 'boundary' not in pm.physical_groups
+  assert pm.periodic_links.shape == (8, 2, 2)
+
+
+def test_refiner_node_counts_and_errors():
+  # core/mesh_refiner_test.py: node counts of conforming refinement
+  for ndim, n, P in [(1, 5, 4), (2, 3, 5), (3, 2, 4), (3, 2, 8)]:
+    rp = refine_premesh(unit_cube_mesh(n, ndim=ndim),
+                        I.Nodes1D.create(P, NT['gll']))
+    assert rp.num_nodes == (n * (P - 1) + 1) ** ndim
+    assert rp.elements.shape == (n ** ndim, P ** ndim)
+    assert rp.order == P - 1
+    # every node is referenced, coordinates of shared nodes agree
+    assert len(np.unique(rp.elements)) == rp.num_nodes
+  rp = refine_premesh(unit_cube_mesh(2, ndim=2), I.Nodes1D.create(3, NT['gl']))
+  assert rp.num_nodes == 4 * 9 and rp.physical_groups == {}
+  with pytest.raises(ValueError, match='order 1'):
+    refine_premesh(rp, I.Nodes1D.create(3, NT['gll']))
+  with pytest.raises(ValueError):
+    Premesh.create(np.zeros((5, 2)), np.zeros((1, 5), dtype=np.int32))
+
+
+def test_exchange_index_builders_known_answers():
+  # core/gather_scatter_test.py:143-288
+  ni = np.array([[0, 1, 2], [2, 3, 4], [4, 5, 6], [6, 7, 8]], dtype=np.int32)
+  gi, ui = GS.get_exchange_indices(ni)
+  np.testing.assert_array_equal(
+      gi, [[2, -1, -1], [0, 2, -1], [-1, 0, 2], [-1, -1, 0]])
+  assert ui is None
+  nip = GS.get_unique_node_indices(ni, np.array([[[0], [8]]]))
+  gi, _ = GS.get_exchange_indices(nip)
+  np.testing.assert_array_equal(
+      gi, [[0, 2, -1, -1], [-1, 0, 2, -1], [-1, -1, 0, 2], [2, -1, -1, 0]])
+  gi, ui = GS.get_exchange_indices(np.arange(3, dtype=np.int32))
+  assert gi.shape == (0,) and ui.shape == (0,) and gi.dtype == np.int32
+  ni = np.array([[0, 1, 5, 6], [1, 2, 6, 7], [2, 3, 7, 8], [3, 4, 8, 9]],
+                dtype=np.int32)
+  links = np.array([[[0, 1], [5, 6]], [[1, 2], [6, 7]], [[2, 3], [7, 8]],
+                    [[3, 4], [8, 9]]], dtype=np.int32)
+  with pytest.raises(NotImplementedError, match='more than once'):
+    GS.get_exchange_indices(GS.get_unique_node_indices(ni, links))
+  with pytest.raises(ValueError):
+    GS.get_exchange_indices(np.zeros((2, 2, 2), dtype=np.int32))
+  np.testing.assert_array_equal(
+      GS.group_by_partitions(np.array([0, 0, 1, 1, 2, 3])),
+      [[0, 1], [2, 3], [4, -1], [5, -1]])
+  nodes, local = GS.get_local_elements(
+      np.array([[[2, 3], [3, 4]], [[4, 5], [5, 2]]]))
+  np.testing.assert_array_equal(nodes, [[2, 3, 4], [2, 4, 5]])
+  np.testing.assert_array_equal(local, [[[0, 1], [1, 2]], [[1, 2], [2, 0]]])
+
+
+def test_premesh_partitioned_known_answers():
+  # core/premesh_test.py:243-376 through finalize_all + the oracle's psum
+  def line(ne, partitions, links=None):
+    nn = ne + 1
+    return Premesh.create(np.linspace(0, 1, nn).reshape(nn, 1),
+                          np.array([[i, i + 1] for i in range(ne)]),
+                          partitions=np.asarray(partitions, dtype=np.int32),
+                          periodic_links=links)
+  pm = line(8, [0, 0, 1, 1, 2, 2, 3, 3])
+  assert pm.is_partitioned()
+  with pytest.raises(ValueError, match='axis_name'):
+    pm.finalize_all()
+  arrs = pm.finalize_all('i')
+  assert arrs['node_indices'].shape == (4, 3)
+  u = np.arange(9.)[arrs['node_indices']]
+  np.testing.assert_array_equal(
+      O.exchange_partitioned(u, arrs['exchange_gather_indices']),
+      [[0, 1, 4], [4, 3, 8], [8, 5, 12], [12, 7, 8]])
+  arrs = line(6, [0, 0, 1, 1, 2, 3]).finalize_all('i')
+  up = np.stack([O.gather(np.arange(7.), row, 0.)
+                 for row in arrs['node_indices']])
+  np.testing.assert_array_equal(
+      up, [[0, 1, 2], [2, 3, 4], [4, 5, 0], [5, 6, 0]])
+  np.testing.assert_array_equal(
+      O.exchange_partitioned(up, arrs['exchange_gather_indices']),
+      [[0, 1, 4], [4, 3, 8], [8, 10, 0], [10, 6, 0]])
+  np.testing.assert_array_equal(
+      arrs['elements'], [[[0, 1], [1, 2]], [[0, 1], [1, 2]],
+                         [[0, 1], [-1, -1]], [[0, 1], [-1, -1]]])
+  arrs = line(8, [0, 0, 1, 1, 2, 2, 3, 3],
+              np.array([[[0], [8]]], dtype=np.int32)).finalize_all('i')
+  u = (1 + np.arange(9.))[arrs['node_indices']]
+  np.testing.assert_array_equal(
+      O.exchange_partitioned(u, arrs['exchange_gather_indices']),
+      [[2, 2, 6], [6, 4, 10], [10, 6, 14], [14, 8, 2]])
+  # physical masks, premesh_test.py:178-200
+  coords = np.array([[0, 0], [0, 1], [1, 0], [1, 1], [0, 2], [2, 1]], float)
+  pm = Premesh.create(coords, np.array([[0, 1, 2, 3], [2, 3, 4, 5]]),
+                      physical_groups={'left': np.array([[0, 1]]),
+                                       'top': np.array([[1, 3], [3, 5]])})
+  masks = pm.finalize_all()['physical_masks']
+  np.testing.assert_array_equal(masks['left'], [1, 1, 0, 0, 0, 0])
+  np.testing.assert_array_equal(masks['top'], [0, 1, 0, 1, 0, 1])
+
+
+def test_mesh_create_on_cpu_holds_arrays_but_refuses_compute():
+  pm = unit_cube_mesh(2, ndim=2)
+  mesh = pm.finalize(device='cpu')
+  assert isinstance(mesh, Mesh) and mesh.ndim == 2 and mesh.order == 1
+  assert mesh.num_nodes == 9 and mesh.num_elements == 4
+  assert mesh.num_nodes_per_element == 4
+  assert mesh.elements.dtype == torch.int32
+  assert mesh.gridpoints_1d == I.Nodes1D.create(2, NT['nc'])
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    mesh.gather(torch.zeros(9, dtype=torch.float64))
+  with pytest.raises(ValueError):
+    mesh.gather(torch.zeros(8, dtype=torch.float64))
+  with pytest.raises(ValueError):
+    Mesh.create(np.zeros((9, 2)), np.zeros((4, 5), dtype=np.int32),
+                device='cpu')
+  m2 = mesh.replace(axis_name='i')
+  assert m2.axis_name == 'i' and mesh.axis_name is None
+
+
+# -------------------------------------------------------------- QExpr algebra
+def _rand(*shape):
+  return torch.randn(*shape, dtype=torch.float64,
+                     generator=torch.Generator().manual_seed(sum(shape)))
+
+
+def test_qexpr_pullbacks_are_exact_transposes():
+  """<form(u, v), 1> == <c0, v> + <c1, grad v> for the reference's forms."""
+  E, Q, d = 3, 5, 3
+  gu, gv = _rand(E, Q, d), _rand(E, Q, d)
+  uv, vv = _rand(E, Q), _rand(E, Q)
+  U, V = _rand(E, Q, d), _rand(E, Q, d)
+  GW, GV = _rand(E, Q, d, d), _rand(E, Q, d, d)
+  ones = torch.ones(E, Q, dtype=torch.float64)
+
+  def ph_val(shape):
+    return QExpr(shape=shape, pullback=lambda ct: (ct, None))
+
+  def ph_grad(shape):
+    return QExpr(shape=shape, pullback=lambda ct: (None, ct))
+
+  # mass: u * v
+  c0, c1 = (QExpr(uv) * ph_val(())).pullback(ones)
+  assert c1 is None and torch.allclose(c0, uv)
+  # stiffness: vdot(grad u, grad v)
+  c0, c1 = torch.vdot(QExpr(gu), ph_grad((d,))).pullback(ones)
+  assert c0 is None and torch.allclose(c1, gu)
+  assert torch.allclose((c1 * gv).sum(), (gu * gv).sum())
+  # vector stiffness: einsum('ij,ij->')
+  c0, c1 = torch.einsum('ij,ij->', QExpr(GW), ph_grad((d, d))).pullback(ones)
+  assert torch.allclose(c1, GW)
+  # convection: einsum('i,ij,j->', u, grad w, v)
+  c0, c1 = torch.einsum('i,ij,j->', QExpr(U), QExpr(GW),
+                        ph_val((d,))).pullback(ones)
+  ref = torch.einsum('mqi,mqij->mqj', U, GW)
+  assert c1 is None and torch.allclose(c0, ref)
+  # divergence forms: trace(grad v) * q, both placeholders
+  c0, c1 = (torch.trace(QExpr(GV)) * ph_val(())).pullback(ones)
+  assert torch.allclose(c0, torch.einsum('mqjj->mq', GV))
+  c0, c1 = (qexpr.trace(ph_grad((d, d))) * QExpr(vv)).pullback(ones)
+  assert torch.allclose(c1, vv[..., None, None] * torch.eye(d, dtype=vv.dtype))
+  # linear combination, scaling, indexing
+  expr = 2.0 * (QExpr(uv) * ph_val(())) - ph_grad((d,))[1] * QExpr(vv) / 4
+  c0, c1 = expr.pullback(ones)
+  assert torch.allclose(c0, 2 * uv)
+  expect = torch.zeros(E, Q, d, dtype=torch.float64)
+  expect[..., 1] = -vv / 4
+  assert torch.allclose(c1, expect)
+  # non-linear / affine uses are rejected
+  with pytest.raises(ValueError):
+    ph_val(()) * ph_val(())
+  with pytest.raises(ValueError):
+    ph_val(()) + 1.0
+  with pytest.raises(ValueError):
+    torch.sin(ph_val(()))
+
+
+def test_qexpr_concrete_arithmetic():
+  E, Q = 2, 4
+  x = QExpr(_rand(E, Q, 3))
+  f = lambda x: sum(x[i] ** 2 for i in range(3)) + torch.sin(x[0]) * 2 - 1
+  got = f(x)
+  ref = (x.val ** 2).sum(-1) + torch.sin(x.val[..., 0]) * 2 - 1
+  assert got.shape == () and torch.allclose(got.val, ref)
+  st = torch.stack([2 * x[0] - x[1], 3 * x[1]])
+  assert st.shape == (2,) and torch.allclose(st.val[..., 1], 3 * x.val[..., 1])
+  assert torch.allclose(torch.vdot(x, x).val, (x.val ** 2).sum(-1))
+  assert torch.allclose((x / 2.0).val, x.val / 2)
+  assert torch.allclose((1.0 / (x * x + 1.0)).val, 1 / (x.val ** 2 + 1))
+  assert len(list(iter(x))) == 3
+
+
+# ------------------------------------------------------------------- C-ABI
+def test_abi_library_exports_every_declared_symbol():
+  from swirl_fem_amd import _lib
+  header = open(os.path.join(ROOT, 'include', 'sfem.h')).read()
+  declared = set(re.findall(r'^(?:int|const char\*)\s+(sfem_\w+)\s*\(', header,
+                            flags=re.M))
+  assert len(declared) >= 20
+  lib = _lib.load()                      # no GPU needed to load / resolve
+  for name in declared:
+    assert hasattr(lib, name), f'{name} declared in sfem.h but not exported'
+  bound = set(_lib.SIGNATURES) | {'sfem_last_error'}
+  assert declared == bound, declared ^ bound
+  assert lib.sfem_abi_version() == _lib.ABI_VERSION
+  # argument checks return an error code + message without touching a GPU
+  rc = lib.sfem_gather(None, None, None, -1, 0.0, 1, None)
+  assert rc == -1 and b'negative' in lib.sfem_last_error()
+  rc = lib.sfem_basis_eval(None, None, None, None, None, None, 1, 4, 3, 3, 1,
+                           0, 1, None)
+  assert rc == -1 and b'ndim' in lib.sfem_last_error()
+
+
+def test_kernels_refuse_cpu_tensors():
+  from swirl_fem_amd import _ops
+  from swirl_fem_amd.linalg.cg import cg
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    _ops.gather(torch.zeros(4, dtype=torch.float64),
+                torch.zeros(2, dtype=torch.int32), 0.0)
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    cg(lambda x: x, torch.ones(3, dtype=torch.float64))
+  with pytest.raises(TypeError):
+    _ops._dtype_code(torch.zeros(1, dtype=torch.int32))
