@@ -12,7 +12,7 @@ from swirl_fem_amd.core import interpolation
 def _mats(interp, like):
   i1, _ = interpolation.matrices_1d(interp.gridpoints_1d, interp.evalpoints_1d)
   g1 = interp._interp_grad_matrix_1d()
-  return tuple(torch.as_tensor(np.ascontiguousarray(m), dtype=like.dtype,
+  return tuple(torch.as_tensor(np.array(m), dtype=like.dtype,
                                device=like.device) for m in (i1, g1))
 
 

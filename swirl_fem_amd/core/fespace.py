@@ -328,6 +328,6 @@ def _device_matrices(interpolator, dtype, device, cache):
                                       interpolator.evalpoints_1d)
     g1 = interpolator._interp_grad_matrix_1d()
     cache[key] = tuple(
-        torch.as_tensor(np.ascontiguousarray(m), dtype=dtype, device=device)
+        torch.as_tensor(np.array(m), dtype=dtype, device=device)
         for m in (i1, g1))
   return cache[key]

@@ -1,0 +1,428 @@
+"""Spectral-element fractional-step Stokes / Navier-Stokes operators.
+
+Drop-in for `swirl_fem/navier_stokes/navier_stokes.py`: `extk_coeffs` :49-58,
+`bdfk_coeffs` :61-70, `BCType` :81-85, `dirichlet_bc` :88-94, `StokesPressure`
+:98-140, `StokesVelocity` :144-245, `StokesSEM` :249-494 (`create`, `B`, `Bi`,
+`A`, `C`, `D_local`, `Dt_local`, `D`, `Dt`, `Q`, `E`, `stokes_one_step`,
+`filter`, `vorticity`).  P_N - P_{N-2} spaces: velocity on GLL(order+1) nodes,
+pressure on GL(order-1) nodes, shared GLL(order+1) quadrature, convection
+over-integrated on GLL(order+1+2) points.
+
+Kernels: the velocity stiffness / mass / Helmholtz operators run the fused
+gather-apply-scatter kernel (`sfem_helmholtz_apply`, all components in one
+launch); convection, divergence and its transpose, the pressure mass matrix and
+the filter go through the generic sum-factorised basis kernels
+(`sfem_basis_eval`, `sfem_basis_eval_t`); both PCG solves of a time step use
+the device-resident CG (`linalg/cg.py`).  `lax.custom_linear_solve` of the
+reference (:436-452) only matters for differentiation through the solve and is
+a plain `cg` call here.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import enum
+from collections.abc import Sequence
+from functools import partial
+from typing import Any
+
+import numpy as np
+import torch
+
+from swirl_fem_amd.core import basis
+from swirl_fem_amd.core import operators
+from swirl_fem_amd.core.fespace import div
+from swirl_fem_amd.core.fespace import FiniteElementSpace
+from swirl_fem_amd.core.fespace import grad
+from swirl_fem_amd.core.interpolation import BarycentricInterpolator
+from swirl_fem_amd.core.interpolation import Nodes1D
+from swirl_fem_amd.core.interpolation import NodeType
+from swirl_fem_amd.core.interpolation import Quadrature1D
+from swirl_fem_amd.core.mesh import Mesh
+from swirl_fem_amd.core.mesh_refiner import refine_premesh
+from swirl_fem_amd.core.premesh import Premesh
+from swirl_fem_amd.linalg.cg import cg
+from swirl_fem_amd import _ops
+
+# pylint: disable=invalid-name
+
+
+def extk_coeffs(k: int) -> np.ndarray:
+  """Linear extrapolation coefficients of order k."""
+  gridpoints = Nodes1D.create(num_points=k + 1, node_type=NodeType.NEWTON_COTES)
+  h = 2 / k
+  evalpoints = Nodes1D.create_single_point(
+      node_value=np.array(1 + h, dtype=np.float64))
+  interpolator = BarycentricInterpolator(
+      ndim=1, gridpoints_1d=gridpoints, evalpoints_1d=evalpoints)
+  return interpolator.interpolation_matrix().reshape((-1))
+
+
+def bdfk_coeffs(k: int) -> np.ndarray:
+  """Backward differentiation formula of order k."""
+  gridpoints = Nodes1D.create(num_points=k + 1, node_type=NodeType.NEWTON_COTES)
+  evalpoints = Nodes1D.create_single_point(
+      node_value=np.array(1., dtype=np.float64))
+  interpolator = BarycentricInterpolator(
+      ndim=1, gridpoints_1d=gridpoints, evalpoints_1d=evalpoints)
+  h = 2 / k
+  return interpolator.interpolation_matrix_grad().reshape((-1)) * h
+
+
+def _pressure_project_out_nullspace(sem, p):
+  """Remove the nullspace (all 1s vector) from p."""
+  w = sem.pressure.exchange(p)
+  q = torch.ones_like(p)
+  return w - (torch.vdot(q, sem.pressure.B(w)) /
+              torch.vdot(q, sem.pressure.B(q))) * q
+
+
+@enum.unique
+class BCType(enum.Enum):
+  """Types of boundary conditions."""
+  DIRICHLET = 'dirichlet'
+  NEUMANN = 'neumann'
+
+
+def dirichlet_bc(mesh: Mesh, boundary_conditions) -> torch.Tensor:
+  """Interior mask (1 inside, 0 on Dirichlet groups), shape (N,)."""
+  interior_mask = torch.ones(mesh.num_nodes, dtype=mesh.dtype,
+                             device=mesh.device)
+  for physical_group, (bctype, unused_bcvalue) in boundary_conditions.items():
+    if bctype == BCType.DIRICHLET:
+      interior_mask = interior_mask * (
+          1 - mesh.physical_masks[physical_group].to(mesh.dtype))
+  return interior_mask
+
+
+def _replace(obj, **kw):
+  return dataclasses.replace(obj, **kw)
+
+
+@dataclasses.dataclass(frozen=True, eq=False)
+class StokesPressure:
+  """Pressure space for the Stokes problem (Gauss-Legendre nodes)."""
+  pspace: FiniteElementSpace
+
+  @classmethod
+  def create(cls, premesh: Premesh, quadrature: Quadrature1D, order: int,
+             device=None, dtype=None) -> 'StokesPressure':
+    gridpoints_1d = Nodes1D.create(num_points=order - 1,
+                                   node_type=NodeType.GAUSS_LEGENDRE)
+    pmesh = refine_premesh(premesh, gridpoints_1d=gridpoints_1d).finalize(
+        device=device, dtype=dtype)
+    return cls(pspace=FiniteElementSpace.create(mesh=pmesh,
+                                                quadrature=quadrature))
+
+  replace = _replace
+
+  def gather(self, p):
+    return self.pspace.mesh.gather(p)
+
+  def scatter(self, p):
+    return self.pspace.mesh.scatter(p)
+
+  def B(self, p):
+    """Apply the pressure mass matrix."""
+    def l(u, v):
+      return lambda x: u(x) * v(x)
+
+    u = self.pspace.scalar_function(self.gather(p))
+    v = self.pspace.scalar_function(None)
+    return self.scatter(self.pspace.local_covector(l, (u, v)))
+
+  def exchange(self, p):
+    """Apply QQ^T."""
+    return self.pspace.mesh.exchange(p)
+
+
+@dataclasses.dataclass(frozen=True, eq=False)
+class StokesVelocity:
+  """Velocity space for the Stokes system (Gauss-Lobatto-Legendre nodes)."""
+  vspace: FiniteElementSpace
+  overint_space: FiniteElementSpace
+  interior_mask: torch.Tensor          # (N, 1)
+  diag_qqt: torch.Tensor               # (N,)
+  num_convection_overint_nodes: int = 2
+
+  @classmethod
+  def create(cls, premesh: Premesh, order: int, boundary_conditions,
+             num_convection_overint_nodes: int = 2, device=None,
+             dtype=None) -> 'StokesVelocity':
+    gridpoints_1d = Nodes1D.create(
+        num_points=order + 1, node_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
+    vmesh = refine_premesh(premesh, gridpoints_1d=gridpoints_1d).finalize(
+        device=device, dtype=dtype)
+    vspace = FiniteElementSpace.create(
+        mesh=vmesh, quadrature=Quadrature1D.create_from_nodes_1d(gridpoints_1d))
+    interior_mask = dirichlet_bc(vmesh, boundary_conditions)[:, None]
+    overint_gridpoints_1d = Nodes1D.create(
+        num_points=gridpoints_1d.num_points + num_convection_overint_nodes,
+        node_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
+    overint_space = FiniteElementSpace.create(
+        mesh=vmesh,
+        quadrature=Quadrature1D.create_from_nodes_1d(overint_gridpoints_1d))
+    diag_qqt = vmesh.scatter(torch.ones(
+        tuple(vmesh.elements.shape), dtype=vmesh.dtype, device=vmesh.device))
+    return cls(vspace=vspace, overint_space=overint_space, diag_qqt=diag_qqt,
+               interior_mask=interior_mask,
+               num_convection_overint_nodes=num_convection_overint_nodes)
+
+  replace = _replace
+
+  @property
+  def local_shape(self):
+    m = self.vspace.mesh
+    return (m.num_elements, m.num_nodes_per_element, m.ndim)
+
+  @property
+  def mesh(self) -> Mesh:
+    return self.vspace.mesh
+
+  def C(self, u):
+    """Apply the convection operator with overintegration."""
+    return self.interior_mask * self.scatter(self.C_local(self.gather(u)))
+
+  def gather(self, u):
+    """(N, d) -> (E, n, d)."""
+    return _ops.gather_rows(u, self.mesh.elements)
+
+  def scatter(self, u_local):
+    """(E, n, d) -> (N, d)."""
+    return _ops.scatter_add(u_local, self.mesh.elements, self.mesh.num_nodes,
+                            ncomp=u_local.shape[-1])
+
+  def exchange(self, u):
+    """Apply QQ^T to every component."""
+    mesh = self.mesh
+    gi = mesh.exchange_gather_indices
+    if gi is None or gi.numel() == 0:
+      return u
+    if mesh.axis_name is None:
+      if mesh.exchange_unique_indices is None:
+        return u.clone()
+      return _ops.exchange_local(u.contiguous(), gi,
+                                 mesh.exchange_unique_indices)
+    from swirl_fem_amd.distributed import comm
+    return comm.neighbor_exchange(u.contiguous(), mesh.neighbor_plan)
+
+  def _fused(self):
+    """Fused operator without mask, or None if the space is not eligible."""
+    if operators.supports_fused(self.vspace) is None:
+      return self.vspace.helmholtz_operator(None)
+    return None
+
+  def A_local(self, u_local):
+    """Apply the velocity stiffness operator locally."""
+    op = self._fused()
+    if op is not None:
+      return op.apply_local(u_local, 0.0, 1.0)
+
+    def a(u, v):
+      return lambda x: torch.einsum('ij,ij->', grad(u)(x), grad(v)(x))
+
+    u = self.vspace.vector_function(u_local)
+    v = self.vspace.vector_function(None)
+    return self.vspace.local_covector(a, (u, v))
+
+  def B_local(self, u_local):
+    """Apply the velocity mass operator locally."""
+    op = self._fused()
+    if op is not None:
+      return op.apply_local(u_local, 1.0, 0.0)
+
+    def l(u, v):
+      return lambda x: torch.vdot(u(x), v(x))
+
+    u = self.vspace.vector_function(u_local)
+    v = self.vspace.vector_function(None)
+    return self.vspace.local_covector(l, (u, v))
+
+  def C_local(self, u_local):
+    """Apply the local convection operator."""
+    def c(u, w, v):
+      return lambda x: torch.einsum('i,ij,j->', u(x), grad(w)(x), v(x))
+
+    u = self.overint_space.vector_function(u_local)
+    v = self.overint_space.vector_function(None)
+    return self.overint_space.local_covector(c, (u, u, v))
+
+
+@dataclasses.dataclass(frozen=True, eq=False)
+class StokesSEM:
+  """Linear operators for a Stokes solver using spectral elements."""
+  velocity: StokesVelocity
+  pressure: StokesPressure
+  velocity_mass_diag: torch.Tensor      # (N, d)
+  _cache: dict = dataclasses.field(default_factory=dict, repr=False,
+                                   compare=False)
+
+  @classmethod
+  def create(cls, premesh: Premesh, boundary_conditions, order: int,
+             num_convection_overint_nodes: int = 2, *, device=None,
+             dtype=None) -> 'StokesSEM':
+    if premesh.order != 1:
+      raise ValueError(f'Expected mesh order 1; got {premesh.order}.')
+    quadrature = Quadrature1D.create(
+        num_points=order + 1, quadrature_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
+    pressure = StokesPressure.create(premesh, quadrature, order, device=device,
+                                     dtype=dtype)
+    velocity = StokesVelocity.create(premesh, order, boundary_conditions,
+                                     num_convection_overint_nodes,
+                                     device=device, dtype=dtype)
+    ones = torch.ones(velocity.local_shape, dtype=velocity.mesh.dtype,
+                      device=velocity.mesh.device)
+    velocity_mass_diag = velocity.scatter(velocity.B_local(ones))
+    return cls(velocity=velocity, pressure=pressure,
+               velocity_mass_diag=velocity_mass_diag)
+
+  def replace(self, **kw):
+    kw.setdefault('_cache', {})
+    return dataclasses.replace(self, **kw)
+
+  # ----------------------------------------------------------------- operators
+  def B(self, u):
+    """Apply the (diagonal) mass operator to a velocity field."""
+    return self.velocity.interior_mask * self.velocity_mass_diag * u
+
+  def Bi(self, u):
+    """Apply the inverse mass operator to a velocity field."""
+    if 'diag_qqti' not in self._cache:
+      self._cache['diag_qqti'] = 1 / self.velocity.exchange(
+          self.velocity_mass_diag)
+    return self._cache['diag_qqti'] * self.velocity.exchange(u)
+
+  def _masked_operator(self):
+    """Fused velocity operator with the Dirichlet rows zeroed, or None."""
+    if 'masked_op' not in self._cache:
+      op = None
+      if operators.supports_fused(self.velocity.vspace) is None:
+        dirichlet = (self.velocity.interior_mask[:, 0] == 0)
+        op = operators.HelmholtzOperator.create(self.velocity.vspace,
+                                                dirichlet)
+      self._cache['masked_op'] = op
+    return self._cache['masked_op']
+
+  def A(self, u):
+    """Apply the stiffness operator to a velocity field."""
+    op = self._masked_operator()
+    if op is not None:
+      return op.apply(u, 0.0, 1.0)
+    return self.velocity.interior_mask * self.velocity.scatter(
+        self.velocity.A_local(self.velocity.gather(u)))
+
+  def H(self, u, mass_coeff: float, mu: float):
+    """Helmholtz operator `mass_coeff * B + mu * A` (reference :431) in one
+    fused kernel; equals `mass_coeff * self.B(u) + mu * self.A(u)`."""
+    op = self._masked_operator()
+    if op is not None:
+      return op.apply(u, mass_coeff, mu)
+    return mass_coeff * self.B(u) + mu * self.A(u)
+
+  def C(self, u):
+    """Apply the convection operator to a velocity field."""
+    return self.velocity.C(u)
+
+  def D_local(self, u_local):
+    """Apply the local operator D."""
+    def b(v, q):
+      return lambda x: div(v)(x) * q(x)
+
+    v = self.velocity.vspace.vector_function(u_local)
+    p = self.pressure.pspace.scalar_function(None)
+    return self.pressure.pspace.local_covector(b, (v, p))
+
+  def Dt_local(self, p_local):
+    """Apply the local operator D^T."""
+    def b(v, q):
+      return lambda x: div(v)(x) * q(x)
+
+    v = self.velocity.vspace.vector_function(None)
+    p = self.pressure.pspace.scalar_function(p_local)
+    return self.velocity.vspace.local_covector(b, (v, p))
+
+  def D(self, u):
+    """Velocity divergence matrix."""
+    return self.pressure.scatter(self.D_local(self.velocity.gather(u)))
+
+  def Dt(self, p):
+    """Apply the pressure gradient operator."""
+    return self.velocity.interior_mask * self.velocity.scatter(
+        self.Dt_local(self.pressure.gather(p)))
+
+  def Q(self, u, dt: float, time_order: int):
+    """Apply the operator Q = (dt / beta_k) B^-1."""
+    beta_k = bdfk_coeffs(time_order)[-1]
+    return (dt / beta_k) * self.Bi(u)
+
+  def E(self, p, dt: float, time_order: int):
+    """Apply the operator E = D Q D^T."""
+    return self.D(self.Q(self.Dt(p), dt=dt, time_order=time_order))
+
+  # ------------------------------------------------------------- time stepping
+  def stokes_one_step(self, us: Sequence[torch.Tensor],
+                      ps: Sequence[torch.Tensor], f, mu: float, dt: float,
+                      time_order: int, alpha: float = 0.05, u_boundary=None,
+                      pressure_preconditioner=None,
+                      project_out_nullspace=True, tol: float = 1e-8,
+                      atol: float = 0) -> tuple[torch.Tensor, torch.Tensor, Any]:
+    """Evolves the Stokes system by one fractional step (reference :350-458)."""
+    if pressure_preconditioner is None and project_out_nullspace:
+      pressure_preconditioner = partial(_pressure_project_out_nullspace, self)
+
+    ext_coeffs = extk_coeffs(k=1)
+    p_ext = sum(float(ext_coeffs[-i]) * ps[-i]
+                for i in range(1, len(ext_coeffs) + 1))
+    f = f + self.Dt(p_ext)
+
+    bdf = bdfk_coeffs(time_order)
+    beta_hist, beta_k = bdf[:-1], float(bdf[-1])
+    H_ = lambda u: self.H(u, beta_k / dt, mu)
+    f = f - self.B((1 / dt) * sum(float(c) * u for c, u in zip(beta_hist, us)))
+    if u_boundary is not None:
+      f = f - H_(u_boundary)
+
+    u_star, info = cg(H_, f, M=self.velocity.exchange, tol=tol, atol=atol)
+    if u_boundary is not None:
+      u_star = u_star + u_boundary
+    aux = {'u_star_info': info}
+
+    u_star = self.filter(u_star, alpha=alpha)
+
+    dp, info = cg(partial(self.E, dt=dt, time_order=time_order),
+                  -self.D(u_star), M=pressure_preconditioner, tol=tol,
+                  atol=atol)
+    aux['dp_info'] = info
+
+    u = u_star + self.Q(self.Dt(dp), dt=dt, time_order=time_order)
+    p = p_ext + dp
+    return u, p, aux
+
+  def filter(self, u, alpha=0.05):
+    """Filter-based stabilisation: blend with the P-1 interpolant (:460-482)."""
+    vmesh = self.velocity.mesh
+    grid = vmesh.gridpoints_1d
+    low = Nodes1D.create(num_points=grid.num_points - 1,
+                         node_type=grid.node_type)
+    low_interp = BarycentricInterpolator(ndim=vmesh.ndim, gridpoints_1d=grid,
+                                         evalpoints_1d=low)
+    high_interp = BarycentricInterpolator(ndim=vmesh.ndim, gridpoints_1d=low,
+                                          evalpoints_1d=grid)
+    u_local = self.velocity.gather(u)
+    filtered_local = basis.interp(high_interp, basis.interp(low_interp,
+                                                            u_local))
+    filtered = (1 / self.velocity.diag_qqt[:, None]) * self.velocity.scatter(
+        filtered_local)
+    return (1 - alpha) * u + alpha * filtered
+
+  def vorticity(self, u):
+    """Vorticity (2D) of a velocity field, averaged at shared nodes."""
+    uf = self.velocity.vspace.vector_function(self.velocity.gather(u))
+
+    def _vorticity(x):
+      g = grad(uf)(x)
+      return g[1, 0] - g[0, 1]
+
+    vort_local = self.velocity.vspace._evaluate(_vorticity)
+    vmesh = self.velocity.vspace.mesh
+    return (1. / self.velocity.diag_qqt) * vmesh.scatter(vort_local)
