@@ -103,9 +103,11 @@ def main():
   ap.add_argument('--n', type=int, default=64, help='elements per dim per GPU')
   ap.add_argument('--p', type=int, default=7, help='polynomial order')
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--stored-factors', action='store_true',
-                  help='read 6 geometric factors per point even on affine '
-                       'elements (the general-geometry kernel path)')
+  ap.add_argument('--geometry', default='auto',
+                  choices=['auto', 'multilinear', 'stored'],
+                  help="'auto': affine / multilinear elements evaluate their "
+                       "geometric factors in registers; 'stored': 6 factors "
+                       "per point are read for every element")
   ap.add_argument('--jitter', type=float, default=0.0,
                   help='smooth mesh deformation amplitude (fraction of h)')
   args = ap.parse_args()
@@ -138,7 +140,7 @@ def main():
   mesh = part.mesh
   fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
   op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
-                              exploit_affine=not args.stored_factors)
+                              geometry=args.geometry)
   setup_s = time.perf_counter() - t_setup
 
   N_local = mesh.num_nodes
@@ -230,18 +232,21 @@ def main():
             'blocks': 'x'.join(map(str, block_grid(world))),
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
             'apply_ms': apply_ms, 'setup_s': setup_s,
-            'geometry': ('%d of %d elements affine: 7 constants per element, '
-                         'quadrature weights applied in-kernel; the rest read '
-                         '6 stored factors per point' % (op.num_affine, E)),
+            'geometry': ('%s: %d affine + %d multilinear elements (factors '
+                         'evaluated in registers), %d with 6 stored factors '
+                         'per point' % (args.geometry, op.num_affine,
+                                        op.num_multilinear, op.num_curved)),
+            'mesh_jitter': args.jitter,
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-            'kernel': 'sfem::helmholtz_kernel<double, 8, 3, true, true>',
+            'kernel': 'sfem::helmholtz_kernel<double, %d, 3, true, true, GM>' % P,
             'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg_bytes,
             'note': ('algorithmic bytes are the stored-6-factor model of '
-                     'SURVEY 8(d) for every element; affine elements move '
-                     'fewer bytes than the model (no per-point factors)'),
+                     'SURVEY 8(d) for every element; affine / multilinear '
+                     'elements move fewer bytes than the model (factors are '
+                     'recomputed in registers, not read)'),
         },
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -152,30 +152,29 @@ int sfem_basis_eval_t(const void* c0, const void* c1, const void* interp1,
  * combination H = (beta_k/dt) B + mu A in one pass over the elements:
  * examples/poisson.py:141-154, navier_stokes.py:220-236, :295-307, :431.
  *
- * Operator data (built once, opaque to the caller):
- *   geo       per-point symmetric factors w detJ (J^-1 J^-T) (3 in 2D, 6 in 3D)
- *             plus w detJ, ndim(ndim+1)/2 + 1 reals per point, for the elements
- *             listed in geo_index (all elements when geo_index is NULL);
- *             written by sfem_helmholtz_setup.
- *   geo_elem  (E, 8) per-element constants detJ (J^-1 J^-T), detJ for AFFINE
- *             elements (constant Jacobian): their per-point factors are that
- *             constant times the tensor quadrature weight, so the kernel never
- *             reads per-point data for them; written by
- *             sfem_helmholtz_setup_affine.  NULL if geo_index is NULL.
- *   geo_index (E,) int32: slot of the element in `geo`, or -1 = affine.
- *   enc       encoded indices (sfem_encode_elements).
- * Three geometry modes are selected by which pointers are non-NULL:
- *   geo only                      every element reads per-point factors
- *   geo_elem only (+ weights)     every element is affine
- *   geo, geo_elem, geo_index      mixed, decided per element                  */
+ * The per-point symmetric factors G = w detJ (J^-1 J^-T) and W = w detJ come
+ * from one of three sources (`geo_mode`):
+ *   SFEM_GEO_POINT        stored: ndim(ndim+1)/2 + 1 reals per point in `geo`
+ *                         (written by sfem_helmholtz_setup).  Element e uses
+ *                         slot geo_index[e] (or e when geo_index is NULL).
+ *   SFEM_GEO_MULTILINEAR  computed in registers from the element's multilinear
+ *                         map (every refine_premesh mesh): `geo_elem` (E, 24),
+ *                         written by sfem_helmholtz_setup_multilinear, plus the
+ *                         1D quadrature weights and node values (host arrays).
+ *   SFEM_GEO_AFFINE       same data, constant Jacobian: G is a per-element
+ *                         constant times the tensor quadrature weight.
+ * `elem_list` (device int32, num_listed entries) restricts a launch to some
+ * elements, so a mesh mixing the kinds is applied by one call per kind.       */
+enum { SFEM_GEO_POINT = 0, SFEM_GEO_AFFINE = 1, SFEM_GEO_MULTILINEAR = 3 };
+
 int sfem_helmholtz_setup(const void* invjac, const void* jacdet,
                          const void* weights_nd /* (Q,) */, void* geo,
                          int64_t num_elements, int ndim, int Q, int dtype,
                          sfem_stream_t stream);
-int sfem_helmholtz_setup_affine(const void* invjac, const void* jacdet,
-                                void* geo_elem /* (E, 8) */,
-                                int64_t num_elements, int ndim, int Q,
-                                int dtype, sfem_stream_t stream);
+/* elem_coords (E, P^ndim, ndim) -> geo_elem (E, 24)                           */
+int sfem_helmholtz_setup_multilinear(const void* elem_coords, void* geo_elem,
+                                     int64_t num_elements, int ndim, int P,
+                                     int dtype, sfem_stream_t stream);
 
 /* enc[i] = node id | flags.  dirichlet (num_nodes,) uint8 or NULL,
  * multiplicity (num_nodes,) int32 = number of slots referencing each node.   */
@@ -184,39 +183,36 @@ int sfem_encode_elements(const int32_t* elements, const uint8_t* dirichlet,
                          int64_t count, sfem_stream_t stream);
 
 typedef struct sfem_helmholtz_args {
-  const void* u;          /* (N, ncomp)                                       */
-  void* out;              /* (N, ncomp); every entry is written by the call   */
-  const int32_t* enc;     /* (E, n) encoded indices                           */
-  const void* geo;        /* per-point factors (see above)                    */
-  const void* geo_elem;   /* (E, 8) or NULL                                   */
-  const int32_t* geo_index; /* (E,) or NULL                                   */
-  const void* dmat;       /* HOST pointer: (P, P) 1D differentiation matrix,  */
-                          /*   row-major, of `dtype`                          */
-  const void* weights;    /* HOST pointer: (P,) 1D quadrature weights of      */
-                          /*   `dtype` (needed with geo_index), or NULL       */
-  int64_t num_elements;
-  int64_t num_nodes;
-  int64_t zero_begin;     /* out[zero_begin:zero_end) is cleared first: must  */
-  int64_t zero_end;       /*   cover every SHARED node and every unreferenced */
-  int32_t ndim;           /*   node                                           */
+  const void* u;          /* (N, ncomp); sfem_helmholtz_local: (E, n, ncomp)  */
+  void* out;              /* same shape as u                                  */
+  const int32_t* enc;     /* (E, n) encoded indices (apply only)              */
+  const void* geo;        /* per-point factors or NULL                        */
+  const void* geo_elem;   /* (E, 24) or NULL                                  */
+  const int32_t* geo_index; /* (E,) slot of element in `geo`, or NULL         */
+  const int32_t* elem_list; /* (num_listed,) element ids, or NULL = all       */
+  const void* dmat;       /* HOST: (P, P) 1D differentiation matrix           */
+  const void* weights;    /* HOST: (P,) 1D quadrature weights, or NULL        */
+  const void* nodes;      /* HOST: (P,) 1D node values, or NULL               */
+  int64_t num_elements;   /* E                                                */
+  int64_t num_listed;     /* length of elem_list                              */
+  int64_t num_nodes;      /* N (apply only)                                   */
+  int64_t zero_begin;     /* apply: out[zero_begin:zero_end) is cleared first;*/
+  int64_t zero_end;       /*   must cover every SHARED / unreferenced node    */
+  int32_t ndim;
   int32_t P;
   int32_t ncomp;
-  int32_t dtype;
+  int32_t dtype;          /* of every real array incl. the host ones          */
+  int32_t geo_mode;       /* SFEM_GEO_*                                       */
+  int32_t reserved;
   double lambda0;         /* mass coefficient                                 */
   double lambda1;         /* stiffness coefficient                            */
 } sfem_helmholtz_args;
 
 int sfem_helmholtz_apply(const sfem_helmholtz_args* args, sfem_stream_t stream);
 
-/* Element-local variant (no gather/scatter): out_local (E, n, ncomp).
- * StokesVelocity.A_local / B_local (navier_stokes.py:220-236).
- * `dmat` and `weights` are HOST pointers as in sfem_helmholtz_args.          */
-int sfem_helmholtz_local(const void* u_local, void* out_local, const void* geo,
-                         const void* geo_elem, const int32_t* geo_index,
-                         const void* dmat, const void* weights,
-                         int64_t num_elements, int ndim, int P, int ncomp,
-                         double lambda0, double lambda1, int dtype,
-                         sfem_stream_t stream);
+/* Element-local variant (no gather/scatter, no mask): u, out are (E, n, ncomp).
+ * StokesVelocity.A_local / B_local (navier_stokes.py:220-236).               */
+int sfem_helmholtz_local(const sfem_helmholtz_args* args, sfem_stream_t stream);
 
 /* ------------------------------------------------------------ CG kernels ---
  * Preconditioned CG of linalg/cg.py:30-97 with device-resident scalars: no

@@ -9,7 +9,7 @@ from swirl_fem_amd import _ops
 
 n = int(os.environ.get('N', '64')); P = int(os.environ.get('P', '8'))
 dev = torch.device('cuda:0')
-part = blocks.build_block_partition(n, P, (1, 1, 1), 0, device=dev)
+part = blocks.build_block_partition(n, P, (1, 1, 1), 0, device=dev, jitter=float(os.environ.get('JITTER', '0')))
 mesh = part.mesh
 grid = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
 fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
@@ -31,15 +31,20 @@ def timeit(label, fn, reps=20):
   print(f'{label:40s} {ms:8.3f} ms  {alg/ms/1e6:8.1f} GB/s alg')
   return ms
 
-op_pp = fes.helmholtz_operator(mesh.physical_masks.get('boundary'), exploit_affine=False)
-print('affine elements', op.num_affine, 'of', E)
-timeit('kernel affine path', lambda: op.apply(u, 0.0, 1.0, out=out, zero=False))
-timeit('kernel per-point path', lambda: op_pp.apply(u, 0.0, 1.0, out=out, zero=False))
-timeit('kernel affine path', lambda: op.apply(u, 0.0, 1.0, out=out, zero=False))
-timeit('apply affine (memset+kernel)', lambda: op.apply(u, 0.0, 1.0, out=out))
-timeit('helmholtz affine', lambda: op.apply(u, 0.7, 1.0, out=out, zero=False))
-timeit('mass only affine', lambda: op.apply(u, 1.0, 0.0, out=out, zero=False))
-timeit('mass only per-point', lambda: op_pp.apply(u, 1.0, 0.0, out=out, zero=False))
+bm = mesh.physical_masks.get('boundary')
+ops = {g: fes.helmholtz_operator(bm, g) for g in ('auto', 'multilinear', 'stored')}
+for g, o in ops.items():
+  print(g, 'affine', o.num_affine, 'multilinear', o.num_multilinear, 'curved', o.num_curved)
+for rep in range(2):
+  for g, o in ops.items():
+    timeit(f'kernel geometry={g}', lambda o=o: o.apply(u, 0.0, 1.0, out=out, zero=False))
+for g, o in ops.items():
+  timeit(f'helmholtz geometry={g}', lambda o=o: o.apply(u, 0.7, 1.0, out=out, zero=False))
+  timeit(f'mass geometry={g}', lambda o=o: o.apply(u, 1.0, 0.0, out=out, zero=False))
+u3 = torch.randn(mesh.num_nodes, 3, dtype=torch.float64, device=dev)
+o3 = torch.empty_like(u3)
+for g, o in ops.items():
+  ms = timeit(f'3-component stiffness geometry={g}', lambda o=o: o.apply(u3, 0.0, 1.0, out=o3, zero=False))
 a = torch.empty(mesh.num_nodes * 10, dtype=torch.float64, device=dev)
 b = torch.empty_like(a)
 ms = timeit('torch copy 7.2GB+7.2GB', lambda: b.copy_(a))

@@ -25,13 +25,16 @@ class HelmholtzArgs(ctypes.Structure):
   """Mirror of `struct sfem_helmholtz_args`."""
   _fields_ = [
       ('u', c_ptr), ('out', c_ptr), ('enc', c_ptr), ('geo', c_ptr),
-      ('geo_elem', c_ptr), ('geo_index', c_ptr), ('dmat', c_ptr),
-      ('weights', c_ptr), ('num_elements', c_i64), ('num_nodes', c_i64),
+      ('geo_elem', c_ptr), ('geo_index', c_ptr), ('elem_list', c_ptr),
+      ('dmat', c_ptr), ('weights', c_ptr), ('nodes', c_ptr),
+      ('num_elements', c_i64), ('num_listed', c_i64), ('num_nodes', c_i64),
       ('zero_begin', c_i64), ('zero_end', c_i64), ('ndim', c_i32),
-      ('P', c_i32), ('ncomp', c_i32), ('dtype', c_i32), ('lambda0', c_dbl),
-      ('lambda1', c_dbl),
+      ('P', c_i32), ('ncomp', c_i32), ('dtype', c_i32), ('geo_mode', c_i32),
+      ('reserved', c_i32), ('lambda0', c_dbl), ('lambda1', c_dbl),
   ]
 
+
+GEO_POINT, GEO_AFFINE, GEO_MULTILINEAR = 0, 1, 3
 
 # name -> argument types (all functions return int unless noted)
 SIGNATURES = {
@@ -56,11 +59,9 @@ SIGNATURES = {
                              c_i32, c_ptr],
     'sfem_encode_elements': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
     'sfem_helmholtz_apply': [ctypes.POINTER(HelmholtzArgs), c_ptr],
-    'sfem_helmholtz_setup_affine': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
-                                    c_i32, c_ptr],
-    'sfem_helmholtz_local': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
-                             c_i64, c_i32, c_i32, c_i32, c_dbl, c_dbl, c_i32,
-                             c_ptr],
+    'sfem_helmholtz_setup_multilinear': [c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                                         c_i32, c_ptr],
+    'sfem_helmholtz_local': [ctypes.POINTER(HelmholtzArgs), c_ptr],
     'sfem_dot': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_dot_accumulate': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_cg_scalars': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr],

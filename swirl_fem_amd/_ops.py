@@ -238,14 +238,17 @@ def encode_elements(elements, dirichlet_u8, multiplicity):
   return enc
 
 
-def helmholtz_setup_affine(invjac, jacdet):
-  dev = _dev(invjac, jacdet)
-  E, Q, ndim, _ = invjac.shape
-  geo_elem = torch.empty((E, 8), dtype=invjac.dtype, device=dev)
+def helmholtz_setup_multilinear(elem_coords, ndim, P):
+  """elem_coords (E, n, d) -> (E, 24) multilinear-map coefficients."""
+  elem_coords = elem_coords.contiguous()
+  dev = _dev(elem_coords)
+  E = elem_coords.shape[0]
+  geo_elem = torch.empty((E, 24), dtype=elem_coords.dtype, device=dev)
   with torch.cuda.device(dev):
-    _lib.check(_lib.load().sfem_helmholtz_setup_affine(
-        _ptr(invjac), _ptr(jacdet), _ptr(geo_elem), E, ndim, Q,
-        _dtype_code(invjac), _stream(dev)), 'sfem_helmholtz_setup_affine')
+    _lib.check(_lib.load().sfem_helmholtz_setup_multilinear(
+        _ptr(elem_coords), _ptr(geo_elem), E, ndim, P,
+        _dtype_code(elem_coords), _stream(dev)),
+        'sfem_helmholtz_setup_multilinear')
   return geo_elem
 
 
@@ -254,48 +257,66 @@ def _host(a, dtype):
   return None if a is None else np.ascontiguousarray(a, dtype=np_dt)
 
 
-def helmholtz_apply(u, out, enc, geo, dmat_host: np.ndarray, ndim, P,
-                    lambda0, lambda1, zero_range, geo_elem=None,
-                    geo_index=None, weights_host=None):
-  """out <- mask * scatter((l0 B + l1 A)_local(gather(u))); returns out."""
-  dev = _dev(u, out, enc, geo, geo_elem, geo_index)
-  ncomp = 1 if u.dim() == 1 else u.shape[-1]
-  dmat_host = _host(dmat_host, u.dtype)
-  weights_host = _host(weights_host, u.dtype)
-  args = _lib.HelmholtzArgs(
-      u=u.data_ptr(), out=out.data_ptr(), enc=enc.data_ptr(),
-      geo=None if geo is None else geo.data_ptr(),
-      geo_elem=None if geo_elem is None else geo_elem.data_ptr(),
-      geo_index=None if geo_index is None else geo_index.data_ptr(),
-      dmat=dmat_host.ctypes.data,
-      weights=None if weights_host is None else weights_host.ctypes.data,
-      num_elements=enc.shape[0], num_nodes=u.shape[0],
+def _hptr(a):
+  return None if a is None else a.ctypes.data
+
+
+def _dptr(t):
+  return None if t is None else t.data_ptr()
+
+
+def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
+                    lambda0, lambda1, zero_range):
+  """Builds `sfem_helmholtz_args`; `part` = dict(geo_mode, geo, geo_elem,
+  geo_index, elem_list), `host` = dict(dmat, weights, nodes) NumPy arrays
+  (kept alive by the caller for the duration of the call)."""
+  ncomp = 1 if u.dim() == (1 if enc is not None else 2) else u.shape[-1]
+  lst = part.get('elem_list')
+  return _lib.HelmholtzArgs(
+      u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),
+      geo=_dptr(part.get('geo')), geo_elem=_dptr(part.get('geo_elem')),
+      geo_index=_dptr(part.get('geo_index')), elem_list=_dptr(lst),
+      dmat=_hptr(host['dmat']), weights=_hptr(host.get('weights')),
+      nodes=_hptr(host.get('nodes')), num_elements=num_elements,
+      num_listed=0 if lst is None else lst.numel(), num_nodes=num_nodes,
       zero_begin=int(zero_range[0]), zero_end=int(zero_range[1]), ndim=ndim,
-      P=P, ncomp=ncomp, dtype=_dtype_code(u), lambda0=float(lambda0),
-      lambda1=float(lambda1))
+      P=P, ncomp=ncomp, dtype=_dtype_code(u), geo_mode=part['geo_mode'],
+      reserved=0, lambda0=float(lambda0), lambda1=float(lambda1))
+
+
+def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
+                    zero_range):
+  """out <- mask * scatter((l0 B + l1 A)_local(gather(u))).
+
+  `parts`: one dict per geometry kind present in the mesh (see
+  `_helmholtz_args`); the shared-node range of `out` is cleared by the first
+  launch only.
+  """
+  dev = _dev(u, out, enc)
+  host = {k: _host(v, u.dtype) for k, v in host.items()}
   with torch.cuda.device(dev):
-    _lib.check(_lib.load().sfem_helmholtz_apply(ctypes.byref(args),
-                                                _stream(dev)),
-               'sfem_helmholtz_apply')
+    for n, part in enumerate(parts):
+      args = _helmholtz_args(u, out, enc, part, host, ndim, P, enc.shape[0],
+                             u.shape[0], lambda0, lambda1,
+                             zero_range if n == 0 else (0, 0))
+      _lib.check(_lib.load().sfem_helmholtz_apply(ctypes.byref(args),
+                                                  _stream(dev)),
+                 'sfem_helmholtz_apply')
   return out
 
 
-def helmholtz_local(u_local, geo, dmat_host: np.ndarray, ndim, P, lambda0,
-                    lambda1, geo_elem=None, geo_index=None, weights_host=None):
+def helmholtz_local(u_local, parts, host, ndim, P, lambda0, lambda1):
   u_local = u_local.contiguous()
-  dev = _dev(u_local, geo, geo_elem, geo_index)
-  ncomp = 1 if u_local.dim() == 2 else u_local.shape[-1]
-  dmat_host = _host(dmat_host, u_local.dtype)
-  weights_host = _host(weights_host, u_local.dtype)
+  dev = _dev(u_local)
+  host = {k: _host(v, u_local.dtype) for k, v in host.items()}
   out = torch.empty_like(u_local)
   with torch.cuda.device(dev):
-    _lib.check(_lib.load().sfem_helmholtz_local(
-        _ptr(u_local), _ptr(out), _ptr(geo), _ptr(geo_elem), _ptr(geo_index),
-        ctypes.c_void_p(dmat_host.ctypes.data),
-        None if weights_host is None else ctypes.c_void_p(
-            weights_host.ctypes.data),
-        u_local.shape[0], ndim, P, ncomp, float(lambda0), float(lambda1),
-        _dtype_code(u_local), _stream(dev)), 'sfem_helmholtz_local')
+    for part in parts:
+      args = _helmholtz_args(u_local, out, None, part, host, ndim, P,
+                             u_local.shape[0], 0, lambda0, lambda1, (0, 0))
+      _lib.check(_lib.load().sfem_helmholtz_local(ctypes.byref(args),
+                                                  _stream(dev)),
+                 'sfem_helmholtz_local')
   return out
 
 

@@ -306,18 +306,20 @@ class FiniteElementSpace:
     return out.reshape((E, self.mesh.num_nodes_per_element) + value_shape)
 
   # -------------------------------------------------------- fused operators
-  def helmholtz_operator(self, dirichlet_mask=None, exploit_affine=True):
+  def helmholtz_operator(self, dirichlet_mask=None, geometry='auto'):
     """Fused `out = mask * scatter((l0 B + l1 A)_local(gather(u)))`.
 
-    `exploit_affine`: elements with a constant Jacobian keep 7 numbers per
-    element instead of 7 per quadrature point (same results to rounding).
+    `geometry`: 'auto' evaluates the geometric factors of affine / multilinear
+    elements in registers and stores 6 factors per point only for curved
+    elements; 'stored' stores them for every element (same results to
+    rounding).
     """
     from swirl_fem_amd.core import operators
     key = ('helmholtz', None if dirichlet_mask is None else id(dirichlet_mask),
-           bool(exploit_affine))
+           geometry)
     if key not in self._cache:
       self._cache[key] = operators.HelmholtzOperator.create(
-          self, dirichlet_mask, exploit_affine)
+          self, dirichlet_mask, geometry)
     return self._cache[key]
 
 

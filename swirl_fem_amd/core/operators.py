@@ -35,69 +35,123 @@ def supports_fused(fespace) -> str | None:
   return None
 
 
-AFFINE_RTOL = 1e-11
+MULTILINEAR_RTOL = {torch.float64: 1e-12, torch.float32: 2e-6}
+AFFINE_RTOL = {torch.float64: 1e-11, torch.float32: 1e-5}
 
 
-def _affine_mask(fespace):
-  """Elements whose Jacobian is constant over the quadrature points."""
-  ij, jd = fespace.invjacs, fespace.jacdets
-  spread = (ij.amax(dim=1) - ij.amin(dim=1)).abs().amax(dim=(1, 2))
-  scale = ij.abs().amax(dim=(1, 2, 3))
-  dspread = jd.amax(dim=1) - jd.amin(dim=1)
-  tol = AFFINE_RTOL if ij.dtype == torch.float64 else 1e-5
-  return (spread <= tol * scale) & (dspread.abs() <= tol * jd.abs().amax(dim=1))
+def classify_geometry(fespace):
+  """Per element: 0 = curved (stored per-point factors), 1 = affine,
+  3 = multilinear image of the reference cube; plus the (E, 24) coefficients.
+
+  An element is multilinear when its nodes coincide with the multilinear
+  interpolant of its 2^d corner nodes (every `refine_premesh` mesh); it is
+  affine when the bilinear/trilinear coefficients vanish as well.
+  """
+  mesh = fespace.mesh
+  d, P = mesh.ndim, mesh.gridpoints_1d.num_points
+  xe = mesh.element_coords()                                   # (E, n, d)
+  coef = _ops.helmholtz_setup_multilinear(xe, d, P)            # (E, 24)
+  x1 = torch.as_tensor(mesh.gridpoints_1d.node_values, dtype=xe.dtype,
+                       device=xe.device)
+  grids = torch.meshgrid(*([x1] * d), indexing='ij')
+  r = [g.reshape(-1) for g in grids]                           # (n,) each
+  if d == 3:
+    mono = torch.stack([r[0], r[1], r[2], r[0] * r[1], r[1] * r[2],
+                        r[0] * r[2], r[0] * r[1] * r[2]], dim=1)   # (n, 7)
+    A = coef[:, :21].reshape(-1, 7, 3)
+    lin, nonlin = A[:, :3], A[:, 3:]
+  else:
+    mono = torch.stack([r[0], r[1], r[0] * r[1]], dim=1)          # (n, 3)
+    A = coef[:, :6].reshape(-1, 3, 2)
+    lin, nonlin = A[:, :2], A[:, 2:]
+  centre = xe.mean(dim=1, keepdim=True) - torch.einsum(
+      'nm,emd->ed', mono, A)[:, None, :] / mono.shape[0]
+  recon = centre + torch.einsum('nm,emd->end', mono, A)
+  size = lin.abs().amax(dim=(1, 2))
+  err = (recon - xe).abs().amax(dim=(1, 2))
+  multi = err <= MULTILINEAR_RTOL[xe.dtype] * size
+  affine = multi & (nonlin.abs().amax(dim=(1, 2)) <=
+                    AFFINE_RTOL[xe.dtype] * size)
+  kind = torch.zeros(xe.shape[0], dtype=torch.int32, device=xe.device)
+  kind[multi] = _GEO_MULTILINEAR
+  kind[affine] = _GEO_AFFINE
+  return kind, coef
+
+
+_GEO_POINT, _GEO_AFFINE, _GEO_MULTILINEAR = 0, 1, 3
 
 
 @dataclasses.dataclass(eq=False)
 class HelmholtzOperator:
   fespace: object
-  geo: torch.Tensor | None       # per-point factors of non-affine elements
+  parts: list                    # one launch description per geometry kind
   enc: torch.Tensor              # (E, n) encoded indices
-  dmat: np.ndarray               # (P, P) host
+  host: dict                     # dmat (P,P), weights (P,), nodes (P,) NumPy
   zero_range: tuple
-  geo_elem: torch.Tensor | None = None    # (E, 8) affine constants
-  geo_index: torch.Tensor | None = None   # (E,) slot in geo or -1
-  weights: np.ndarray | None = None       # (P,) host
   num_affine: int = 0
+  num_multilinear: int = 0
+  num_curved: int = 0
 
   @classmethod
   def create(cls, fespace, dirichlet_mask=None,
-             exploit_affine=True) -> 'HelmholtzOperator':
+             geometry='auto') -> 'HelmholtzOperator':
+    """geometry: 'auto' (per element: affine / multilinear / stored factors),
+    'multilinear' (no affine shortcut) or 'stored' (6 factors per point for
+    every element, the general-geometry path)."""
     why = supports_fused(fespace)
     if why is not None:
       raise NotImplementedError(f'fused Helmholtz kernel unavailable: {why}')
+    if geometry not in ('auto', 'multilinear', 'stored'):
+      raise ValueError(f'unknown geometry mode {geometry!r}')
     mesh = fespace.mesh
+    E = mesh.num_elements
     w = torch.as_tensor(fespace.quadrature.weights_nd(mesh.ndim),
                         dtype=fespace.dtype, device=fespace.device)
-    geo_elem = geo_index = None
-    num_affine = 0
-    affine = _affine_mask(fespace) if exploit_affine else None
-    if affine is not None and bool(affine.any()):
-      num_affine = int(affine.sum())
-      general = ~affine
-      geo_index = torch.where(
-          affine, torch.full_like(affine, -1, dtype=torch.int64),
-          torch.cumsum(general, 0) - 1).to(torch.int32).contiguous()
-      geo_elem = _ops.helmholtz_setup_affine(fespace.invjacs, fespace.jacdets)
-      if num_affine < mesh.num_elements:
-        geo = _ops.helmholtz_setup(fespace.invjacs[general].contiguous(),
-                                   fespace.jacdets[general].contiguous(), w)
-      else:
-        geo = geo_index = None         # every element affine
+    if geometry == 'stored':
+      kind = torch.zeros(E, dtype=torch.int32, device=fespace.device)
+      coef = None
     else:
-      geo = _ops.helmholtz_setup(fespace.invjacs, fespace.jacdets, w)
+      kind, coef = classify_geometry(fespace)
+      if geometry == 'multilinear':
+        kind = torch.where(kind == _GEO_AFFINE,
+                           torch.full_like(kind, _GEO_MULTILINEAR), kind)
+    counts = {k: int((kind == k).sum()) for k in
+              (_GEO_POINT, _GEO_AFFINE, _GEO_MULTILINEAR)}
+    parts = []
+    for k in (_GEO_AFFINE, _GEO_MULTILINEAR, _GEO_POINT):
+      if counts[k] == 0:
+        continue
+      part = {'geo_mode': k}
+      sel = kind == k
+      if counts[k] < E:
+        part['elem_list'] = torch.nonzero(sel).reshape(-1).to(
+            torch.int32).contiguous()
+      if k == _GEO_POINT:
+        if counts[k] < E:
+          part['geo'] = _ops.helmholtz_setup(
+              fespace.invjacs[sel].contiguous(),
+              fespace.jacdets[sel].contiguous(), w)
+          part['geo_index'] = (torch.cumsum(sel, 0) - 1).to(
+              torch.int32).contiguous()
+        else:
+          part['geo'] = _ops.helmholtz_setup(fespace.invjacs, fespace.jacdets,
+                                             w)
+      else:
+        part['geo_elem'] = coef
+      parts.append(part)
     plan = mesh.assembly_plan()
     mask = None
     if dirichlet_mask is not None:
       mask = torch.as_tensor(dirichlet_mask, device=fespace.device)
       mask = (mask != 0).to(torch.uint8).contiguous()
     enc = _ops.encode_elements(mesh.elements, mask, plan.multiplicity)
-    return cls(fespace=fespace, geo=geo, enc=enc,
-               dmat=fespace.interpolator._differentiation_matrix_1d(),
-               zero_range=plan.zero_range, geo_elem=geo_elem,
-               geo_index=geo_index,
-               weights=np.asarray(fespace.quadrature.weights),
-               num_affine=num_affine)
+    host = {'dmat': fespace.interpolator._differentiation_matrix_1d(),
+            'weights': np.asarray(fespace.quadrature.weights),
+            'nodes': np.asarray(mesh.gridpoints_1d.node_values)}
+    return cls(fespace=fespace, parts=parts, enc=enc, host=host,
+               zero_range=plan.zero_range, num_affine=counts[_GEO_AFFINE],
+               num_multilinear=counts[_GEO_MULTILINEAR],
+               num_curved=counts[_GEO_POINT])
 
   def apply(self, u, lambda0=0.0, lambda1=1.0, out=None, *, zero=True):
     """u (N,) or (N, nc) -> mask * scatter((l0 B + l1 A)_local(gather(u))).
@@ -113,15 +167,13 @@ class HelmholtzOperator:
     if out is None:
       out = torch.empty_like(u)
     return _ops.helmholtz_apply(
-        u, out, self.enc, self.geo, self.dmat, mesh.ndim,
+        u, out, self.enc, self.parts, self.host, mesh.ndim,
         mesh.gridpoints_1d.num_points, lambda0, lambda1,
-        self.zero_range if zero else (0, 0), self.geo_elem, self.geo_index,
-        self.weights)
+        self.zero_range if zero else (0, 0))
 
   def apply_local(self, u_local, lambda0=0.0, lambda1=1.0):
     """Element-local action (E, n[, nc]) -> (E, n[, nc]); no gather/scatter."""
     mesh = self.fespace.mesh
     return _ops.helmholtz_local(
-        u_local.to(self.fespace.dtype), self.geo, self.dmat, mesh.ndim,
-        mesh.gridpoints_1d.num_points, lambda0, lambda1, self.geo_elem,
-        self.geo_index, self.weights)
+        u_local.to(self.fespace.dtype), self.parts, self.host, mesh.ndim,
+        mesh.gridpoints_1d.num_points, lambda0, lambda1)

@@ -44,13 +44,18 @@ struct HelmholtzParams {
   const T* u;            // (N, nc) or (E, n, nc) when !GS
   T* out;
   const int32_t* enc;    // (E, n) encoded indices (GS only)
-  const T* geo;          // per-point factors of the non-affine elements
-  const T* geo_elem;     // (E, 8) per-element constants, or null
-  const int32_t* geo_index;  // (E,) slot in `geo`, -1 = affine; or null
+  const T* geo;          // per-point factors (elements with geo_index >= 0)
+  const T* geo_elem;     // (E, 24) multilinear map coefficients, or null
+  const int32_t* geo_index;  // (E,) slot in `geo`, -1 affine, -2 multilinear
+  int geo_mode;          // GeoMode
   const T* dmat_host;    // (P, P) on the HOST; travels as a kernel argument
-  const T* weights_host; // (P,) quadrature weights on the HOST (affine path)
-  int64_t num_elements;
-  int ncomp;
+  const T* weights_host; // (P,) quadrature weights on the HOST
+  const T* nodes_host;   // (P,) 1D node values on the HOST
+  int64_t num_elements;  // elements processed by this launch
+  const int32_t* elem_list;  // their ids, or null = 0..num_elements-1
+  int ncomp;             // components handled inside the kernel
+  int comp_stride;       // stride between nodes of u / out (>= ncomp)
+  int comp;              // first component
   T lambda0, lambda1;
   int debug_flags;       // reserved for A/B experiments (SFEM_DEBUG_FLAGS)
 };
@@ -107,14 +112,18 @@ struct DMat {
   static constexpr int PH = P / 2, PC = P - P / 2;
   T e[PH * PC];   // E[r][m], r < PH, m < PC
   T o[PC * PH];   // O[r][m], r < PC, m < PH
-  T w[P];         // 1D quadrature weights (affine elements)
+  T w[P];         // 1D quadrature weights
+  T x[P];         // 1D node values (on-the-fly geometry)
 };
 
 template <typename T, int P>
-inline DMat<T, P> make_dmat(const T* d, const T* w) {
+inline DMat<T, P> make_dmat(const T* d, const T* w, const T* x) {
   constexpr int PH = P / 2, PC = P - P / 2;
   DMat<T, P> dm;
-  for (int r = 0; r < P; ++r) dm.w[r] = w ? w[r] : T(0);
+  for (int r = 0; r < P; ++r) {
+    dm.w[r] = w ? w[r] : T(0);
+    dm.x[r] = x ? x[r] : T(0);
+  }
   for (int r = 0; r < PH; ++r)
     for (int m = 0; m < PC; ++m)
       dm.e[r * PC + m] = m < PH ? (d[r * P + m] + d[r * P + P - 1 - m]) / 2
@@ -169,15 +178,237 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nblocks) {
   return start + k;
 }
 
-// GM (geometry mode): 0 = every element reads per-point factors, 1 = every
-// element is affine, 2 = mixed (per element, via geo_index).
+// Geometry modes.  The symmetric factors G = w detJ (J^-1 J^-T) (and W = w detJ)
+// of a quadrature point come from one of three sources:
+//   GEO_POINT        6 (+1) stored values per point, streamed from HBM
+//   GEO_MULTILINEAR  the element is the image of the reference cube under a
+//                    multilinear map (every mesh produced by refine_premesh
+//                    is): 7 coefficient vectors per ELEMENT; the Jacobian,
+//                    its adjugate and G are evaluated in registers per point
+//                    (~65 flops) -- bytes traded for flops on a kernel whose
+//                    VALU is ~25 % busy
+//   GEO_AFFINE       multilinear with constant Jacobian: G is a per-element
+//                    constant times the tensor quadrature weight
+// A mesh that mixes the three kinds is processed by up to three launches, each
+// over its own element list (`elem_list`), so every kernel stays specialised.
+enum GeoMode { GEO_POINT = 0, GEO_AFFINE = 1, GEO_MULTILINEAR = 3 };
+
+template <typename T, int P>
+__device__ __forceinline__ T lane_pick(const T (&v)[P], int idx) {
+  // runtime index into a by-value kernel argument would push the struct to
+  // scratch; a select chain keeps it in SGPRs
+  T r = T(0);
+#pragma unroll
+  for (int q = 0; q < P; ++q) r = idx == q ? v[q] : r;
+  return r;
+}
+
+// Per-lane geometry state of one element.
+template <typename T, int P, int DIM, int GM>
+struct ElemGeom {
+  static constexpr int NG = DIM == 3 ? 6 : 3;
+  static constexpr int NPT = DIM == 3 ? P * P * P : P * P;
+  static constexpr int TPE = DIM == 3 ? P * P : P;
+  static constexpr bool HAS_POINT = GM == GEO_POINT;
+  static constexpr bool HAS_AFFINE = GM == GEO_AFFINE;
+  static constexpr bool HAS_MULTI = GM == GEO_MULTILINEAR;
+  typedef T Pair __attribute__((ext_vector_type(2)));
+
+  const char* base;    // per-point factors of this element
+  uint32_t lane_off;   // byte offset of this lane inside one factor plane
+  T wbc;               // product of the in-plane quadrature weights
+  T cst[HAS_AFFINE ? 7 : 1];       // affine: G upper triangle / w, det
+  // multilinear: rows of the Jacobian are R0 (constant along the line),
+  // R1 = p1 + r q1, R2 = p2 + r q2 with r the axis-0 node coordinate
+  T r0[HAS_MULTI ? DIM : 1], p1[HAS_MULTI ? DIM : 1], q1[HAS_MULTI ? DIM : 1],
+      p2[HAS_MULTI && DIM == 3 ? 3 : 1], q2[HAS_MULTI && DIM == 3 ? 3 : 1];
+
+  __device__ __forceinline__ bool is_affine() const { return HAS_AFFINE; }
+  __device__ __forceinline__ bool is_multi() const { return HAS_MULTI; }
+
+  __device__ __forceinline__ void init(const HelmholtzParams<T>& prm,
+                                       const DMat<T, P>& dm, int64_t e,
+                                       bool active, int i, int j, int t) {
+    int64_t slot = e;
+    if (HAS_POINT && prm.geo_index) slot = active ? prm.geo_index[e] : 0;
+    base = reinterpret_cast<const char*>(prm.geo) +
+           (HAS_POINT ? slot * (int64_t)(NG + 1) * NPT * sizeof(T) : 0);
+    lane_off = (uint32_t)(t * sizeof(T));
+    wbc = T(0);
+    if (GM == GEO_POINT || !active) return;
+    if (HAS_AFFINE || HAS_MULTI) {
+      {
+        const T wj = lane_pick<T, P>(dm.w, j);
+        wbc = DIM == 3 ? lane_pick<T, P>(dm.w, i) * wj : wj;
+        const T* A = prm.geo_elem + e * 24;   // A1..A7 (3D) / A1..A3 (2D)
+        if (DIM == 3) {
+          const T s = lane_pick<T, P>(dm.x, i), tt = lane_pick<T, P>(dm.x, j);
+          T a0[3], a1[3], a2[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const T A1 = A[c], A2 = A[3 + c], A3 = A[6 + c], A4 = A[9 + c],
+                    A5 = A[12 + c], A6 = A[15 + c], A7 = A[18 + c];
+            // d/dr = A1 + A4 s + A6 t + A7 s t;  d/ds = (A2 + A5 t) + r (A4 + A7 t)
+            // d/dt = (A3 + A5 s) + r (A6 + A7 s)
+            a0[c] = A1 + A4 * s + (A6 + A7 * s) * tt;
+            a1[c] = A2 + A5 * tt;
+            a2[c] = A3 + A5 * s;
+            if (HAS_MULTI) {
+              r0[c] = a0[c];
+              p1[c] = a1[c];
+              q1[c] = A4 + A7 * tt;
+              p2[c] = a2[c];
+              q2[c] = A6 + A7 * s;
+            }
+          }
+          if (HAS_AFFINE && is_affine()) {
+            // constant Jacobian rows a0, a1, a2
+            T c0[3] = {a1[1] * a2[2] - a1[2] * a2[1],
+                       a1[2] * a2[0] - a1[0] * a2[2],
+                       a1[0] * a2[1] - a1[1] * a2[0]};
+            T c1[3] = {a2[1] * a0[2] - a2[2] * a0[1],
+                       a2[2] * a0[0] - a2[0] * a0[2],
+                       a2[0] * a0[1] - a2[1] * a0[0]};
+            T c2[3] = {a0[1] * a1[2] - a0[2] * a1[1],
+                       a0[2] * a1[0] - a0[0] * a1[2],
+                       a0[0] * a1[1] - a0[1] * a1[0]};
+            const T det = a0[0] * c0[0] + a0[1] * c0[1] + a0[2] * c0[2];
+            const T inv = T(1) / det;
+            cst[0] = inv * (c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+            cst[1] = inv * (c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2]);
+            cst[2] = inv * (c0[0] * c2[0] + c0[1] * c2[1] + c0[2] * c2[2]);
+            cst[3] = inv * (c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+            cst[4] = inv * (c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2]);
+            cst[5] = inv * (c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
+            cst[6] = det;
+          }
+        } else {
+          const T s = lane_pick<T, P>(dm.x, j);   // axis-1 coordinate
+          T a0[2], a1[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const T A1 = A[c], A2 = A[2 + c], A3 = A[4 + c];
+            a0[c] = A1 + A3 * s;      // d/dr, constant along the line
+            a1[c] = A2;               // d/ds = A2 + r A3
+            if (HAS_MULTI) { r0[c] = a0[c]; p1[c] = A2; q1[c] = A3; }
+          }
+          if (HAS_AFFINE && is_affine()) {
+            const T det = a0[0] * a1[1] - a0[1] * a1[0];
+            const T inv = T(1) / det;
+            // columns of the adjugate: C0 = (d, -c), C1 = (-b, a)
+            cst[0] = inv * (a1[1] * a1[1] + a1[0] * a1[0]);
+            cst[1] = -inv * (a1[1] * a0[1] + a1[0] * a0[0]);
+            cst[2] = inv * (a0[1] * a0[1] + a0[0] * a0[0]);
+            cst[6] = det;
+          }
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ Pair pair_at(int pi, int a) const {
+    const char* b = base + (size_t)pi * 2 * NPT * sizeof(T);
+    return *reinterpret_cast<const Pair*>(
+        b + (2 * lane_off + (uint32_t)(2 * a * TPE * sizeof(T))));
+  }
+
+  // Factors at the lane's node of slice a: G[0..NG) upper triangle, W.
+  // want_g / want_w are compile-time after inlining in the callers.
+  __device__ __forceinline__ void factors(const DMat<T, P>& dm, int a,
+                                          bool want_g, bool want_w,
+                                          T (&G)[6], T& Wm) const {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) G[f] = T(0);
+    Wm = T(0);
+    if (HAS_AFFINE && is_affine()) {
+      const T sc = wbc * dm.w[a];
+      if (want_g) {
+        if (DIM == 3) {
+#pragma unroll
+          for (int f = 0; f < 6; ++f) G[f] = cst[f] * sc;
+        } else {
+          G[0] = cst[0] * sc; G[1] = cst[1] * sc; G[3] = cst[2] * sc;
+        }
+      }
+      if (want_w) Wm = cst[6] * sc;
+      return;
+    }
+    if (HAS_MULTI && is_multi()) {
+      const T r = dm.x[a];
+      const T wq = wbc * dm.w[a];
+      if (DIM == 3) {
+        T R1[3], R2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          R1[c] = p1[c] + r * q1[c];
+          R2[c] = p2[c] + r * q2[c];
+        }
+        const T c0[3] = {R1[1] * R2[2] - R1[2] * R2[1],
+                         R1[2] * R2[0] - R1[0] * R2[2],
+                         R1[0] * R2[1] - R1[1] * R2[0]};
+        const T det = r0[0] * c0[0] + r0[1] * c0[1] + r0[2] * c0[2];
+        if (want_w) Wm = wq * det;
+        if (want_g) {
+          const T c1[3] = {R2[1] * r0[2] - R2[2] * r0[1],
+                           R2[2] * r0[0] - R2[0] * r0[2],
+                           R2[0] * r0[1] - R2[1] * r0[0]};
+          const T c2[3] = {r0[1] * R1[2] - r0[2] * R1[1],
+                           r0[2] * R1[0] - r0[0] * R1[2],
+                           r0[0] * R1[1] - r0[1] * R1[0]};
+          const T sc = wq / det;
+          G[0] = sc * (c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+          G[1] = sc * (c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2]);
+          G[2] = sc * (c0[0] * c2[0] + c0[1] * c2[1] + c0[2] * c2[2]);
+          G[3] = sc * (c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+          G[4] = sc * (c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2]);
+          G[5] = sc * (c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
+        }
+      } else {
+        const T R1x = p1[0] + r * q1[0], R1y = p1[1] + r * q1[1];
+        const T det = r0[0] * R1y - r0[1] * R1x;
+        if (want_w) Wm = wq * det;
+        if (want_g) {
+          const T sc = wq / det;
+          G[0] = sc * (R1y * R1y + R1x * R1x);
+          G[1] = -sc * (R1y * r0[1] + R1x * r0[0]);
+          G[3] = sc * (r0[1] * r0[1] + r0[0] * r0[0]);
+        }
+      }
+      return;
+    }
+    if (HAS_POINT) {
+      // stored in pairs so that fp64 reads are 16 bytes per lane:
+      //   3D: (G00,G01) (G02,G11) (G12,G22), then W;  2D: (G00,G01) (G11,W)
+      if (DIM == 3) {
+        if (want_g) {
+          const Pair p0 = pair_at(0, a), pa = pair_at(1, a), pb = pair_at(2, a);
+          G[0] = p0.x; G[1] = p0.y; G[2] = pa.x; G[3] = pa.y;
+          G[4] = pb.x; G[5] = pb.y;
+        }
+        if (want_w) {
+          const char* b = base + (size_t)6 * NPT * sizeof(T);
+          Wm = *reinterpret_cast<const T*>(
+              b + (lane_off + (uint32_t)(a * TPE * sizeof(T))));
+        }
+      } else {
+        const Pair pa = pair_at(1, a);
+        if (want_g) {
+          const Pair p0 = pair_at(0, a);
+          G[0] = p0.x; G[1] = p0.y; G[3] = pa.x;
+        }
+        Wm = pa.y;
+      }
+    }
+  }
+};
+
 template <typename T, int P, int DIM, bool GS, bool SCALAR, int GM>
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   using Tile = HelmholtzTile<T, P, DIM>;
   constexpr int TPE = Tile::TPE, SA = Tile::SA, SB = Tile::SB;
-  constexpr int EPB = Tile::EPB, W = Tile::ELEM_WORDS, NG = Tile::NGEO;
+  constexpr int EPB = Tile::EPB, W = Tile::ELEM_WORDS;
   constexpr int N = DIM == 3 ? P * P * P : P * P;        // nodes per element
   __shared__ T lds[2 * EPB * W];
 
@@ -186,9 +417,12 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   const int t = tid - el * TPE;             // lane within the element
   const int i = DIM == 3 ? t / P : 0;
   const int j = DIM == 3 ? t - i * P : t;
-  const int64_t e0 = (int64_t)blockIdx.x * EPB;   // wave-uniform
   const bool lane_ok = el < EPB;            // tail lanes of a padded block
-  const bool active = lane_ok && e0 + el < prm.num_elements;
+  const int64_t work = (int64_t)blockIdx.x * EPB + (lane_ok ? el : 0);
+  const bool active = lane_ok && work < prm.num_elements;
+  // element id: wave-uniform when an element fills whole waves
+  const int64_t e =
+      prm.elem_list ? (active ? (int64_t)prm.elem_list[work] : 0) : work;
 
   T* s0 = lds + (lane_ok ? el : 0) * 2 * W;    // becomes the axis-1 result
   T* s1 = s0 + W;                              // becomes the axis-2 result
@@ -196,90 +430,46 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   // SCALAR: one component known at compile time (no component loop, so the
   // compiler has nothing to hoist out of it and spill)
   const int nc = SCALAR ? 1 : prm.ncomp;
+  const int cs = prm.comp_stride;
   const bool has_mass = prm.lambda0 != T(0);
   const bool has_stiff = prm.lambda1 != T(0);
 
   // Owner layout: this lane holds nodes (a, i, j), a = 0..P-1, i.e. element
-  // slots a*TPE + t.  All per-element arrays are addressed as a wave-uniform
-  // base (SGPR pair) + one 32-bit per-lane byte offset + compile-time constant.
-  // Affine elements (constant Jacobian) keep 7 numbers per ELEMENT instead of
-  // per point: G(q) = w_q * (detJ J^-1 J^-T), W(q) = w_q detJ with w_q the
-  // tensor quadrature weight.  `geo_index` maps the other elements to their
-  // slot in the per-point array.
-  const int64_t e_lane = e0 + (lane_ok ? el : 0);
-  int64_t gslot = e_lane;
-  if (GM == 2) gslot = active ? prm.geo_index[e_lane] : 0;
-  const bool affine = GM == 1 || (GM == 2 && gslot < 0);
-  T cg[GM == 0 ? 1 : 7];
-  T wbc = T(0);
-  if (GM != 0 && affine) {
-    const T* ce = prm.geo_elem + e_lane * 8;
-#pragma unroll
-    for (int f = 0; f < 7; ++f) cg[f] = ce[f];
-    // per-lane lookup by select chain (a runtime index into a by-value kernel
-    // argument would force the struct into scratch)
-    T wi = T(0), wj = T(0);
-#pragma unroll
-    for (int r = 0; r < P; ++r) {
-      wi = i == r ? dm.w[r] : wi;
-      wj = j == r ? dm.w[r] : wj;
-    }
-    wbc = DIM == 3 ? wi * wj : wj;
-  }
-  const char* geo0 = reinterpret_cast<const char*>(
-      prm.geo + (GM == 1 || affine ? 0 : gslot) * (int64_t)(NG + 1) * N);
-  uint32_t geo_off_v = (uint32_t)(t * sizeof(T));
-  uint32_t slot_off_v = (uint32_t)(el * N + t);
-  const uint32_t& geo_off = geo_off_v;
+  // slots a*TPE + t.  Per-element arrays are addressed as a wave-uniform base
+  // + one 32-bit per-lane offset + compile-time constant.
+  ElemGeom<T, P, DIM, GM> geom;
+  geom.init(prm, dm, e, active, i, j, t);
+  uint32_t slot_off_v = (uint32_t)t;
   const uint32_t& slot_off = slot_off_v;
-  // Geometric factors are stored in pairs so that fp64 reads are 16 bytes per
-  // lane (1 KiB per wave-instruction):
-  //   3D: [pair 0..2][Q][2] = (G00,G01) (G02,G11) (G12,G22), then W [Q]
-  //   2D: [pair 0..1][Q][2] = (G00,G01) (G11,W)
-  // Each access is a wave-uniform (SGPR) base + one shared lane offset + a
-  // small immediate.
-  typedef T Pair __attribute__((ext_vector_type(2)));
-  auto geo_pair = [&](int pi, int a) -> Pair {
-    const char* base = geo0 + (size_t)pi * 2 * N * sizeof(T);
-    const Pair* ptr = reinterpret_cast<const Pair*>(
-        base + (2 * geo_off + (uint32_t)(2 * a * TPE * sizeof(T))));
-    // streamed once: non-temporal so the factors do not evict the gathered
-    // nodal values that neighbouring elements re-read from L2 / MALL
-    return *ptr;
-  };
-  auto geo_mass = [&](int a) -> T {
-    if (DIM == 2) return geo_pair(1, a).y;
-    const char* base = geo0 + (size_t)6 * N * sizeof(T);
-    return *reinterpret_cast<const T*>(
-        base + (geo_off + (uint32_t)(a * TPE * sizeof(T))));
-  };
 
   uint32_t enc[P];
   if (GS) {
-    const int32_t* enc0 = prm.enc + e0 * N;
+    const int32_t* enc0 = prm.enc + e * N;
 #pragma unroll
     for (int a = 0; a < P; ++a)
       enc[a] = active ? (uint32_t)enc0[slot_off + a * TPE]
                       : (uint32_t)SFEM_IDX_PAD;
   }
-  const T* ul0 = GS ? nullptr : prm.u + e0 * N * nc;
-  T* ol0 = GS ? nullptr : prm.out + e0 * N * nc;
+  const T* ul0 = GS ? nullptr : prm.u + e * N * cs + prm.comp;
+  T* ol0 = GS ? nullptr : prm.out + e * N * cs + prm.comp;
+  const T* ug = prm.u + prm.comp;
+  T* og = prm.out + prm.comp;
 
   for (int k = 0; k < nc; ++k) {
     if (!SCALAR) {
-      // keep address arithmetic and flag tests inside the component loop:
-      // hoisted out of it they occupy ~100 registers and spill
-      asm volatile("" : "+v"(geo_off_v), "+v"(slot_off_v));
-      if (GM != 0) asm volatile("" : "+v"(wbc));
+      // keep address arithmetic, flag tests and geometry products inside the
+      // component loop: hoisted out of it they occupy ~100 registers and spill
+      asm volatile("" : "+v"(geom.lane_off), "+v"(slot_off_v));
+      if (GM != GEO_POINT) asm volatile("" : "+v"(geom.wbc));
     }
     T ua[P], acc[P];
 #pragma unroll
     for (int a = 0; a < P; ++a) {
       if (GS) {
         const uint32_t id = enc[a] & SFEM_IDX_MASK;
-        ua[a] = id == SFEM_IDX_PAD ? T(0) : prm.u[(int64_t)id * nc + k];
+        ua[a] = id == SFEM_IDX_PAD ? T(0) : ug[(int64_t)id * cs + k];
       } else {
-        ua[a] = active ? ul0[(slot_off + a * TPE) * nc + k] : T(0);
+        ua[a] = active ? ul0[(slot_off + a * TPE) * cs + k] : T(0);
       }
     }
     if (has_stiff) {
@@ -312,43 +502,28 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         for (int m = 0; m < P; ++m) line[m * SB] = y[m];
       }
       __syncthreads();
-      // pointwise: w = G * (reference gradient), G symmetric
+      // pointwise: w = G * (reference gradient), G symmetric; the mass term
+      // rides along when both are requested
       T w0[P];
 #pragma unroll
-      for (int a = 0; a < P; ++a) w0[a] = T(0);
+      for (int a = 0; a < P; ++a) { w0[a] = T(0); acc[a] = T(0); }
       if (active) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
           const int o = a * SA + i * SB + j;
+          T G[6], Wm;
+          constexpr bool FUSE_W = GM != GEO_POINT;
+          geom.factors(dm, a, true, FUSE_W && has_mass, G, Wm);
+          if (FUSE_W && has_mass) acc[a] = prm.lambda0 * Wm * ua[a];
           if (DIM == 3) {
             const T g0 = d0[a], g1 = s0[o], g2 = s1[o];
-            T G00 = T(0), G01 = T(0), G02 = T(0), G11 = T(0), G12 = T(0),
-              G22 = T(0);
-            if (GM != 0 && affine) {
-              const T sc = wbc * dm.w[a];
-              G00 = cg[0] * sc; G01 = cg[1] * sc; G02 = cg[2] * sc;
-              G11 = cg[3] * sc; G12 = cg[4] * sc; G22 = cg[5] * sc;
-            } else if (GM != 1) {
-              const Pair p0 = geo_pair(0, a), p1 = geo_pair(1, a),
-                         p2 = geo_pair(2, a);
-              G00 = p0.x; G01 = p0.y; G02 = p1.x; G11 = p1.y;
-              G12 = p2.x; G22 = p2.y;
-            }
-            w0[a] = G00 * g0 + G01 * g1 + G02 * g2;
-            s0[o] = G01 * g0 + G11 * g1 + G12 * g2;
-            s1[o] = G02 * g0 + G12 * g1 + G22 * g2;
+            w0[a] = G[0] * g0 + G[1] * g1 + G[2] * g2;
+            s0[o] = G[1] * g0 + G[3] * g1 + G[4] * g2;
+            s1[o] = G[2] * g0 + G[4] * g1 + G[5] * g2;
           } else {
             const T g0 = d0[a], g1 = s0[o];
-            T G00 = T(0), G01 = T(0), G11 = T(0);
-            if (GM != 0 && affine) {
-              const T sc = wbc * dm.w[a];
-              G00 = cg[0] * sc; G01 = cg[1] * sc; G11 = cg[2] * sc;
-            } else if (GM != 1) {
-              const Pair p0 = geo_pair(0, a), p1 = geo_pair(1, a);
-              G00 = p0.x; G01 = p0.y; G11 = p1.x;
-            }
-            w0[a] = G00 * g0 + G01 * g1;
-            s0[o] = G01 * g0 + G11 * g1;
+            w0[a] = G[0] * g0 + G[1] * g1;
+            s0[o] = G[1] * g0 + G[3] * g1;
           }
         }
       }
@@ -371,28 +546,37 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
 #pragma unroll
         for (int m = 0; m < P; ++m) line[m * SB] = y[m];
       }
-      line_apply<T, P, true>(dmat, w0, acc);
+      T dt0[P];
+      line_apply<T, P, true>(dmat, w0, dt0);
       __syncthreads();
       if (lane_ok) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
           const int o = a * SA + i * SB + j;
-          acc[a] += s0[o];
-          if (DIM == 3) acc[a] += s1[o];
-          acc[a] *= prm.lambda1;
+          T v = dt0[a] + s0[o];
+          if (DIM == 3) v += s1[o];
+          acc[a] += prm.lambda1 * v;
+        }
+      }
+      if (GM == GEO_POINT && has_mass && active) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+          T G[6], Wm;
+          geom.factors(dm, a, false, true, G, Wm);
+          acc[a] += prm.lambda0 * Wm * ua[a];
         }
       }
     } else {
 #pragma unroll
       for (int a = 0; a < P; ++a) acc[a] = T(0);
-    }
-    if (has_mass && active) {
+      if (has_mass && active) {
 #pragma unroll
-      for (int a = 0; a < P; ++a)
-        acc[a] += prm.lambda0 *
-                  ((GM != 0 && affine) ? cg[GM == 0 ? 0 : 6] * wbc * dm.w[a]
-                                       : (GM != 1 ? geo_mass(a) : T(0))) *
-                  ua[a];
+        for (int a = 0; a < P; ++a) {
+          T G[6], Wm;
+          geom.factors(dm, a, false, true, G, Wm);
+          acc[a] = prm.lambda0 * Wm * ua[a];
+        }
+      }
     }
     // direct-stiffness summation
 #pragma unroll
@@ -404,7 +588,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         asm volatile("" : "+v"(ea));
         const uint32_t id = ea & SFEM_IDX_MASK;
         if (id != SFEM_IDX_PAD) {
-          T* dst = prm.out + (int64_t)id * nc + k;
+          T* dst = og + (int64_t)id * cs + k;
           const bool dirichlet = ea & SFEM_IDX_DIRICHLET;
           if (ea & SFEM_IDX_SHARED) {
             if (!dirichlet) unsafeAtomicAdd(dst, acc[a]);
@@ -413,7 +597,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
           }
         }
       } else if (active) {
-        ol0[(slot_off + a * TPE) * nc + k] = acc[a];
+        ol0[(slot_off + a * TPE) * cs + k] = acc[a];
       }
     }
     if (k + 1 < nc) __syncthreads();
@@ -428,20 +612,31 @@ int launch_helmholtz(const HelmholtzParams<T>& prm, hipStream_t stream) {
     set_error("helmholtz: too many workgroups (%lld)", (long long)groups);
     return SFEM_EINVAL;
   }
-  const DMat<T, P> dm = make_dmat<T, P>(prm.dmat_host, prm.weights_host);
+  const DMat<T, P> dm =
+      make_dmat<T, P>(prm.dmat_host, prm.weights_host, prm.nodes_host);
   const dim3 grid((unsigned)groups), block(Tile::BLOCK);
-  const int gm = prm.geo_elem == nullptr ? 0 : (prm.geo == nullptr ? 1 : 2);
-#define SFEM_LAUNCH_GM(SC, GMV)                                              \
+#define SFEM_LAUNCH_GM(SC, GMV, PRM)                                          \
   hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, SC, GMV>), grid, block, \
-                     0, stream, prm, dm)
+                     0, stream, PRM, dm)
   if (prm.ncomp == 1) {
-    if (gm == 0) SFEM_LAUNCH_GM(true, 0);
-    else if (gm == 1) SFEM_LAUNCH_GM(true, 1);
-    else SFEM_LAUNCH_GM(true, 2);
+    switch (prm.geo_mode) {
+      case GEO_POINT: SFEM_LAUNCH_GM(true, GEO_POINT, prm); break;
+      case GEO_AFFINE: SFEM_LAUNCH_GM(true, GEO_AFFINE, prm); break;
+      default: SFEM_LAUNCH_GM(true, GEO_MULTILINEAR, prm); break;
+    }
+  } else if (prm.geo_mode == GEO_POINT) {
+    SFEM_LAUNCH_GM(false, GEO_POINT, prm);     // factors read once per element
+  } else if (prm.geo_mode == GEO_AFFINE) {
+    SFEM_LAUNCH_GM(false, GEO_AFFINE, prm);
   } else {
-    if (gm == 0) SFEM_LAUNCH_GM(false, 0);
-    else if (gm == 1) SFEM_LAUNCH_GM(false, 1);
-    else SFEM_LAUNCH_GM(false, 2);
+    // on-the-fly geometry: one single-component launch per component keeps
+    // the kernel inside its register budget (no per-point data is re-read)
+    for (int k = 0; k < prm.ncomp; ++k) {
+      HelmholtzParams<T> one = prm;
+      one.ncomp = 1;
+      one.comp = prm.comp + k;
+      SFEM_LAUNCH_GM(true, GEO_MULTILINEAR, one);
+    }
   }
 #undef SFEM_LAUNCH_GM
   SFEM_LAUNCH_CHECK();

@@ -66,48 +66,89 @@ encode_kernel(const int32_t* __restrict__ elements,
   }
 }
 
-// geo_elem[e] = { detJ (J^-1 J^-T) upper triangle (ref-direction indices),
-// padded to 6 entries, detJ, 0 } taken at the element's first quadrature point.
+// geo_elem[e] (24 reals) = coefficient vectors of the multilinear map through
+// the element's 2^d corner nodes, x(r,s,t) = c + A1 r + A2 s + A3 t + A4 rs +
+// A5 st + A6 rt + A7 rst (3D: A1..A7, 21 reals; 2D: x = c + A1 r + A2 s + A3 rs,
+// 6 reals), r = axis 0, s = axis 1, t = axis 2 of the element's node lattice.
 template <typename T>
 __global__ void __launch_bounds__(256)
-helmholtz_setup_affine_kernel(const T* __restrict__ invjac,
-                              const T* __restrict__ jacdet,
-                              T* __restrict__ geo_elem, int64_t num_elements,
-                              int d, int Q) {
+helmholtz_setup_multilinear_kernel(const T* __restrict__ elem_coords,
+                                   T* __restrict__ geo_elem,
+                                   int64_t num_elements, int d, int P) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= num_elements) return;
-  const T* ij = invjac + e * Q * d * d;
-  const T det = jacdet[e * Q];
-  T* g = geo_elem + e * 8;
-  int f = 0;
-  for (int i = 0; i < d; ++i)
-    for (int k = i; k < d; ++k) {
-      T acc = T(0);
-      for (int j = 0; j < d; ++j) acc += ij[j * d + i] * ij[j * d + k];
-      g[f++] = det * acc;
+  int n = 1;
+  for (int q = 0; q < d; ++q) n *= P;
+  const T* x = elem_coords + e * n * d;
+  T* g = geo_elem + e * 24;
+  for (int q = 0; q < 24; ++q) g[q] = T(0);
+  const int L = P - 1;
+  if (d == 3) {
+    for (int c = 0; c < 3; ++c) {
+      T A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int cr = 0; cr < 2; ++cr)
+        for (int cs = 0; cs < 2; ++cs)
+          for (int ct = 0; ct < 2; ++ct) {
+            const T v = x[((cr * L * P + cs * L) * P + ct * L) * 3 + c];
+            const T sr = cr ? 1 : -1, ss = cs ? 1 : -1, st = ct ? 1 : -1;
+            A[1] += sr * v; A[2] += ss * v; A[3] += st * v;
+            A[4] += sr * ss * v; A[5] += ss * st * v; A[6] += sr * st * v;
+            A[7] += sr * ss * st * v;
+          }
+      for (int q = 1; q < 8; ++q) g[(q - 1) * 3 + c] = A[q] / 8;
     }
-  for (; f < 6; ++f) g[f] = T(0);
-  g[6] = det;
-  g[7] = T(0);
+  } else if (d == 2) {
+    for (int c = 0; c < 2; ++c) {
+      T A1 = 0, A2 = 0, A3 = 0;
+      for (int cr = 0; cr < 2; ++cr)
+        for (int cs = 0; cs < 2; ++cs) {
+          const T v = x[(cr * L * P + cs * L) * 2 + c];
+          const T sr = cr ? 1 : -1, ss = cs ? 1 : -1;
+          A1 += sr * v; A2 += ss * v; A3 += sr * ss * v;
+        }
+      g[c] = A1 / 4; g[2 + c] = A2 / 4; g[4 + c] = A3 / 4;
+    }
+  }
 }
 
+struct HelmholtzCall {
+  const void* u; void* out; const int32_t* enc; const void* geo;
+  const void* geo_elem; const int32_t* geo_index; const int32_t* elem_list;
+  const void* dmat; const void* weights; const void* nodes;
+  int64_t num_elements; int ndim, P, ncomp, geo_mode; double l0, l1; bool gs;
+};
+
 template <typename T>
-static int run_helmholtz(const void* u, void* out, const int32_t* enc,
-                         const void* geo, const void* geo_elem,
-                         const int32_t* geo_index, const void* dmat,
-                         const void* weights, int64_t E, int ndim, int P,
-                         int ncomp, double l0, double l1, bool gs,
-                         hipStream_t stream) {
-  const char* dbg = getenv("SFEM_DEBUG_FLAGS");
-  HelmholtzParams<T> prm{(const T*)u,        (T*)out,         enc,
-                         (const T*)geo,      (const T*)geo_elem, geo_index,
-                         (const T*)dmat,     (const T*)weights, E,
-                         ncomp,              (T)l0,           (T)l1,
-                         dbg ? atoi(dbg) : 0};
-  if (ndim == 3) return dispatch_helmholtz<T, 3>(prm, P, gs, stream);
-  if (ndim == 2) return dispatch_helmholtz<T, 2>(prm, P, gs, stream);
-  set_error("helmholtz: ndim=%d (fused kernel supports 2 and 3)", ndim);
+static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
+  HelmholtzParams<T> prm{};
+  prm.u = (const T*)c.u; prm.out = (T*)c.out; prm.enc = c.enc;
+  prm.geo = (const T*)c.geo; prm.geo_elem = (const T*)c.geo_elem;
+  prm.geo_index = c.geo_index; prm.geo_mode = c.geo_mode;
+  prm.dmat_host = (const T*)c.dmat; prm.weights_host = (const T*)c.weights;
+  prm.nodes_host = (const T*)c.nodes; prm.num_elements = c.num_elements;
+  prm.elem_list = c.elem_list; prm.ncomp = c.ncomp; prm.comp_stride = c.ncomp;
+  prm.comp = 0; prm.lambda0 = (T)c.l0; prm.lambda1 = (T)c.l1;
+  prm.debug_flags = 0;
+  if (c.ndim == 3) return dispatch_helmholtz<T, 3>(prm, c.P, c.gs, stream);
+  if (c.ndim == 2) return dispatch_helmholtz<T, 2>(prm, c.P, c.gs, stream);
+  set_error("helmholtz: ndim=%d (fused kernel supports 2 and 3)", c.ndim);
   return SFEM_EUNSUPPORTED;
+}
+
+static int check_geometry(const char* who, int geo_mode, const void* geo,
+                          const void* geo_elem, const void* weights,
+                          const void* nodes) {
+  if (geo_mode == SFEM_GEO_POINT) {
+    SFEM_REQUIRE(geo, "%s: per-point geometry needs `geo`", who);
+  } else if (geo_mode == SFEM_GEO_AFFINE || geo_mode == SFEM_GEO_MULTILINEAR) {
+    SFEM_REQUIRE(geo_elem && weights && nodes,
+                 "%s: on-the-fly geometry needs geo_elem, weights and nodes",
+                 who);
+  } else {
+    set_error("%s: unknown geo_mode %d", who, geo_mode);
+    return SFEM_EINVAL;
+  }
+  return SFEM_OK;
 }
 
 }  // namespace sfem
@@ -179,78 +220,69 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
         (size_t)(a->zero_end - a->zero_begin) * a->ncomp * esz,
         as_stream(stream)));
   if (a->num_elements == 0) return SFEM_OK;
-  SFEM_REQUIRE(a->u && a->enc && a->dmat && (a->geo || a->geo_elem),
-               "sfem_helmholtz_apply: null pointer");
-  SFEM_REQUIRE(!a->geo_elem || a->weights,
-               "sfem_helmholtz_apply: geo_elem needs the quadrature weights");
-  SFEM_REQUIRE(!(a->geo_elem && a->geo) || a->geo_index,
-               "sfem_helmholtz_apply: mixed geometry needs geo_index");
-  if (a->dtype == SFEM_F64)
-    return run_helmholtz<double>(a->u, a->out, a->enc, a->geo, a->geo_elem,
-                                 a->geo_index, a->dmat, a->weights,
-                                 a->num_elements, a->ndim, a->P, a->ncomp,
-                                 a->lambda0, a->lambda1, true,
-                                 as_stream(stream));
-  return run_helmholtz<float>(a->u, a->out, a->enc, a->geo, a->geo_elem,
-                              a->geo_index, a->dmat, a->weights,
-                              a->num_elements, a->ndim, a->P, a->ncomp,
-                              a->lambda0, a->lambda1, true, as_stream(stream));
+  SFEM_REQUIRE(a->u && a->enc && a->dmat, "sfem_helmholtz_apply: null pointer");
+  int rc = check_geometry("sfem_helmholtz_apply", a->geo_mode, a->geo,
+                          a->geo_elem, a->weights, a->nodes);
+  if (rc) return rc;
+  const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
+  SFEM_REQUIRE(work >= 0 && work <= a->num_elements,
+               "sfem_helmholtz_apply: bad element list length");
+  if (work == 0) return SFEM_OK;
+  HelmholtzCall c{a->u, a->out, a->enc, a->geo, a->geo_elem, a->geo_index,
+                  a->elem_list, a->dmat, a->weights, a->nodes, work, a->ndim,
+                  a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, true};
+  if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
+  return run_helmholtz<float>(c, as_stream(stream));
 }
 
-int sfem_helmholtz_setup_affine(const void* invjac, const void* jacdet,
-                                void* geo_elem, int64_t num_elements, int ndim,
-                                int Q, int dtype, sfem_stream_t stream) {
-  SFEM_REQUIRE(num_elements >= 0 && ndim >= 1 && ndim <= 3 && Q >= 1,
-               "sfem_helmholtz_setup_affine: bad sizes");
+int sfem_helmholtz_setup_multilinear(const void* elem_coords, void* geo_elem,
+                                     int64_t num_elements, int ndim, int P,
+                                     int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(num_elements >= 0 && (ndim == 2 || ndim == 3) && P >= 2 &&
+                   P <= SFEM_MAX_P,
+               "sfem_helmholtz_setup_multilinear: bad sizes");
   if (num_elements == 0) return SFEM_OK;
-  SFEM_REQUIRE(invjac && jacdet && geo_elem,
-               "sfem_helmholtz_setup_affine: null pointer");
+  SFEM_REQUIRE(elem_coords && geo_elem,
+               "sfem_helmholtz_setup_multilinear: null pointer");
   const unsigned grid = (unsigned)((num_elements + 255) / 256);
   if (dtype == SFEM_F64)
-    hipLaunchKernelGGL(helmholtz_setup_affine_kernel<double>, dim3(grid),
-                       dim3(256), 0, as_stream(stream), (const double*)invjac,
-                       (const double*)jacdet, (double*)geo_elem, num_elements,
-                       ndim, Q);
+    hipLaunchKernelGGL(helmholtz_setup_multilinear_kernel<double>, dim3(grid),
+                       dim3(256), 0, as_stream(stream),
+                       (const double*)elem_coords, (double*)geo_elem,
+                       num_elements, ndim, P);
   else if (dtype == SFEM_F32)
-    hipLaunchKernelGGL(helmholtz_setup_affine_kernel<float>, dim3(grid),
-                       dim3(256), 0, as_stream(stream), (const float*)invjac,
-                       (const float*)jacdet, (float*)geo_elem, num_elements,
-                       ndim, Q);
+    hipLaunchKernelGGL(helmholtz_setup_multilinear_kernel<float>, dim3(grid),
+                       dim3(256), 0, as_stream(stream),
+                       (const float*)elem_coords, (float*)geo_elem,
+                       num_elements, ndim, P);
   else {
-    set_error("sfem_helmholtz_setup_affine: unknown dtype %d", dtype);
+    set_error("sfem_helmholtz_setup_multilinear: unknown dtype %d", dtype);
     return SFEM_EINVAL;
   }
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }
 
-int sfem_helmholtz_local(const void* u_local, void* out_local, const void* geo,
-                         const void* geo_elem, const int32_t* geo_index,
-                         const void* dmat, const void* weights,
-                         int64_t num_elements, int ndim, int P, int ncomp,
-                         double lambda0, double lambda1, int dtype,
-                         sfem_stream_t stream) {
-  SFEM_REQUIRE(num_elements >= 0 && ncomp >= 1 && ncomp <= 8,
+int sfem_helmholtz_local(const sfem_helmholtz_args* a, sfem_stream_t stream) {
+  SFEM_REQUIRE(a, "sfem_helmholtz_local: null args");
+  SFEM_REQUIRE(a->num_elements >= 0 && a->ncomp >= 1 && a->ncomp <= 8,
                "sfem_helmholtz_local: bad sizes");
-  if (num_elements == 0) return SFEM_OK;
-  SFEM_REQUIRE(u_local && out_local && dmat && (geo || geo_elem),
-               "sfem_helmholtz_local: null pointer");
-  SFEM_REQUIRE(!geo_elem || weights,
-               "sfem_helmholtz_local: geo_elem needs the quadrature weights");
-  SFEM_REQUIRE(!(geo_elem && geo) || geo_index,
-               "sfem_helmholtz_local: mixed geometry needs geo_index");
-  if (dtype == SFEM_F64)
-    return run_helmholtz<double>(u_local, out_local, nullptr, geo, geo_elem,
-                                 geo_index, dmat, weights, num_elements, ndim,
-                                 P, ncomp, lambda0, lambda1, false,
-                                 as_stream(stream));
-  if (dtype == SFEM_F32)
-    return run_helmholtz<float>(u_local, out_local, nullptr, geo, geo_elem,
-                                geo_index, dmat, weights, num_elements, ndim,
-                                P, ncomp, lambda0, lambda1, false,
-                                as_stream(stream));
-  set_error("sfem_helmholtz_local: unknown dtype %d", dtype);
-  return SFEM_EINVAL;
+  SFEM_REQUIRE(a->dtype == SFEM_F32 || a->dtype == SFEM_F64,
+               "sfem_helmholtz_local: unknown dtype %d", a->dtype);
+  if (a->num_elements == 0) return SFEM_OK;
+  SFEM_REQUIRE(a->u && a->out && a->dmat, "sfem_helmholtz_local: null pointer");
+  int rc = check_geometry("sfem_helmholtz_local", a->geo_mode, a->geo,
+                          a->geo_elem, a->weights, a->nodes);
+  if (rc) return rc;
+  const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
+  SFEM_REQUIRE(work >= 0 && work <= a->num_elements,
+               "sfem_helmholtz_local: bad element list length");
+  if (work == 0) return SFEM_OK;
+  HelmholtzCall c{a->u, a->out, nullptr, a->geo, a->geo_elem, a->geo_index,
+                  a->elem_list, a->dmat, a->weights, a->nodes, work, a->ndim,
+                  a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, false};
+  if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
+  return run_helmholtz<float>(c, as_stream(stream));
 }
 
 }  // extern "C"

@@ -333,14 +333,19 @@ def _helmholtz_ref(ofes, u, l0, l1, dirichlet):
     (2, 2, 11), (2, 2, 12), (3, 3, 2), (3, 2, 3), (3, 3, 4), (3, 2, 5),
     (3, 2, 6), (3, 2, 7), (3, 3, 8), (3, 2, 9), (3, 2, 10), (3, 1, 11),
     (3, 2, 12)])
-def test_fused_helmholtz_fp64(ndim, n, P):
+@pytest.mark.parametrize('geometry', ['auto', 'stored'])
+def test_fused_helmholtz_fp64(ndim, n, P, geometry):
   rp = make_case(ndim, n, P, seed=11, scramble=True)
   mesh, fes, ofes = spaces(rp, P, P, 'gll')
   rng = np.random.default_rng(12)
   u = rng.standard_normal(mesh.num_nodes)
   bmask = mesh.physical_masks['boundary'].cpu().numpy()
-  op_free = fes.helmholtz_operator(None)
-  op_bc = fes.helmholtz_operator(mesh.physical_masks['boundary'])
+  op_free = fes.helmholtz_operator(None, geometry)
+  op_bc = fes.helmholtz_operator(mesh.physical_masks['boundary'], geometry)
+  if geometry == 'auto':     # vertex-jittered elements are multilinear
+    assert op_free.num_multilinear == mesh.num_elements
+  else:
+    assert op_free.num_curved == mesh.num_elements
   for l0, l1, op, msk in [(0., 1., op_free, None), (1., 0., op_free, None),
                           (0.7, 1.3, op_bc, bmask)]:
     got = op.apply(dev(u), l0, l1)
@@ -362,55 +367,74 @@ def test_fused_helmholtz_fp32_and_vector(ndim, n, P):
   rng = np.random.default_rng(14)
   for dtype in (torch.float32, torch.float64):
     mesh, fes, ofes = spaces(rp, P, P, 'gll', dtype)
-    op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
     bmask = mesh.physical_masks['boundary'].cpu().numpy()
-    tol = 1e-10 if dtype == torch.float64 else 2e-5
-    for nc in (1, 2, 3):
-      u = rng.standard_normal((mesh.num_nodes, nc))
-      uu = u[:, 0] if nc == 1 else u
-      got = op.apply(dev(uu, dtype), 0.5, 1.5)
-      assert relerr(got, _helmholtz_ref(ofes, uu, 0.5, 1.5, bmask)) < tol
-    ul = rng.standard_normal(rp.elements.shape + (ndim,))
-    got = op.apply_local(dev(ul, dtype), 0.0, 1.0)
-    assert relerr(got, ofes.stiffness_local(ul)) < tol
+    tol = 1e-10 if dtype == torch.float64 else 3e-5
+    for geometry in ('auto', 'stored'):
+      op = fes.helmholtz_operator(mesh.physical_masks['boundary'], geometry)
+      for nc in (1, 2, 3):
+        u = rng.standard_normal((mesh.num_nodes, nc))
+        uu = u[:, 0] if nc == 1 else u
+        got = op.apply(dev(uu, dtype), 0.5, 1.5)
+        assert relerr(got, _helmholtz_ref(ofes, uu, 0.5, 1.5, bmask)) < tol
+      ul = rng.standard_normal(rp.elements.shape + (ndim,))
+      got = op.apply_local(dev(ul, dtype), 0.0, 1.0)
+      assert relerr(got, ofes.stiffness_local(ul)) < tol
 
 
 @pytest.mark.parametrize('ndim,n,P', [(2, 4, 5), (3, 3, 4), (3, 3, 8)])
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
-def test_fused_helmholtz_affine_elements(ndim, n, P, dtype):
-  """Affine elements use 7 constants per element; mixed meshes use both."""
+def test_fused_helmholtz_geometry_kinds(ndim, n, P, dtype):
+  """Affine / multilinear elements evaluate their factors in registers,
+  curved elements read stored factors; a mesh may mix all three."""
   rng = np.random.default_rng(19)
-  tol = 1e-10 if dtype == torch.float64 else 2e-5
-  for mode in ('structured', 'sheared', 'mixed'):
+  tol = 1e-10 if dtype == torch.float64 else 3e-5
+  for mode in ('structured', 'sheared', 'vertex', 'curved', 'mixed'):
     pm = unit_cube_mesh(n, ndim=ndim)
     x = pm.node_coords.copy()
     if mode == 'sheared':       # affine map of the whole mesh: still affine
       A = np.eye(ndim) + 0.3 * rng.uniform(-1, 1, (ndim, ndim))
       x = x @ A.T + 0.1
-    if mode == 'mixed':         # move one interior vertex: 2^d elements bend
+    if mode in ('vertex', 'mixed'):   # move one interior vertex: multilinear
       centre = np.argmin(((x - 0.5) ** 2).sum(-1))
       x[centre] += 0.1 / n
     rp = refine_premesh(pm.replace(node_coords=x),
                         Nodes1D.create(P, NT['gll']))
+    if mode in ('curved', 'mixed'):   # bend the high-order nodes themselves
+      xc = rp.node_coords.copy()
+      bump = 0.03 * np.sin(np.pi * xc[:, 0]) * np.sin(2 * np.pi * xc[:, 1])
+      if mode == 'mixed':
+        bump = bump * (xc[:, 0] < 1.0 / n + 1e-9)   # first layer of elements
+      xc[:, -1] += bump * np.prod(xc * (1 - xc), axis=1) * 4 ** ndim
+      rp = rp.replace(node_coords=xc)
     mesh, fes, ofes = spaces(rp, P, P, 'gll', dtype)
     bmask = mesh.physical_masks['boundary'].cpu().numpy()
-    op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
-    op_pp = fes.helmholtz_operator(mesh.physical_masks['boundary'],
-                                   exploit_affine=False)
-    if mode == 'mixed':
-      assert 0 < op.num_affine < mesh.num_elements
-    elif dtype == torch.float64:
-      assert op.num_affine == mesh.num_elements
-    assert op_pp.num_affine == 0
+    ops = {g: fes.helmholtz_operator(mesh.physical_masks['boundary'], g)
+           for g in ('auto', 'multilinear', 'stored')}
+    E, op = mesh.num_elements, ops['auto']
+    assert op.num_affine + op.num_multilinear + op.num_curved == E
+    assert ops['stored'].num_curved == E
+    if dtype == torch.float64:
+      if mode in ('structured', 'sheared'):
+        assert op.num_affine == E and ops['multilinear'].num_multilinear == E
+      if mode == 'vertex':
+        assert op.num_multilinear == 2 ** ndim and op.num_curved == 0
+      if mode == 'curved':
+        assert op.num_curved > 0
+      if mode == 'mixed':
+        assert min(op.num_affine, op.num_multilinear, op.num_curved) > 0
     for nc in (1, ndim):
       u = rng.standard_normal((mesh.num_nodes, nc))
       uu = u[:, 0] if nc == 1 else u
       ref = _helmholtz_ref(ofes, uu, 0.4, 1.1, bmask)
-      assert relerr(op.apply(dev(uu, dtype), 0.4, 1.1), ref) < tol, mode
-      assert relerr(op_pp.apply(dev(uu, dtype), 0.4, 1.1), ref) < tol, mode
+      for g, o in ops.items():
+        assert relerr(o.apply(dev(uu, dtype), 0.4, 1.1), ref) < tol, (mode, g)
     ul = rng.standard_normal(rp.elements.shape)
     ref = 0.2 * ofes.mass_local(ul) + ofes.stiffness_local(ul)
-    assert relerr(op.apply_local(dev(ul, dtype), 0.2, 1.0), ref) < tol, mode
+    for g, o in ops.items():
+      assert relerr(o.apply_local(dev(ul, dtype), 0.2, 1.0), ref) < tol, (mode,
+                                                                          g)
+      assert relerr(o.apply_local(dev(ul, dtype), 1.0, 0.0),
+                    ofes.mass_local(ul)) < tol, (mode, g)
 
 
 def test_fused_helmholtz_padded_elements_and_errors():
