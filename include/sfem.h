@@ -176,10 +176,14 @@ int sfem_helmholtz_setup_multilinear(const void* elem_coords, void* geo_elem,
                                      int64_t num_elements, int ndim, int P,
                                      int dtype, sfem_stream_t stream);
 
-/* enc[i] = node id | flags.  dirichlet (num_nodes,) uint8 or NULL,
- * multiplicity (num_nodes,) int32 = number of slots referencing each node.   */
+/* enc[i] = node id | flags.  dirichlet (num_nodes,) uint8 or NULL.  The SHARED
+ * flag (accumulate instead of store) is set for slots whose node has
+ * multiplicity[node] > 1 (multiplicity (num_nodes,) int32 = number of slots
+ * referencing the node), or, when slot_shared (count,) uint8 is given, for the
+ * slots it marks (coloured assembly: every slot but the first toucher).       */
 int sfem_encode_elements(const int32_t* elements, const uint8_t* dirichlet,
-                         const int32_t* multiplicity, int32_t* enc,
+                         const int32_t* multiplicity,
+                         const uint8_t* slot_shared, int32_t* enc,
                          int64_t count, sfem_stream_t stream);
 
 typedef struct sfem_helmholtz_args {
@@ -203,10 +207,19 @@ typedef struct sfem_helmholtz_args {
   int32_t ncomp;
   int32_t dtype;          /* of every real array incl. the host ones          */
   int32_t geo_mode;       /* SFEM_GEO_*                                       */
-  int32_t reserved;
+  int32_t colored;        /* apply: != 0 if the listed elements share no node */
+                          /*   with each other (one colour class per launch,  */
+                          /*   launches stream-ordered): SHARED slots then    */
+                          /*   read-modify-write `out` without atomics, the   */
+                          /*   sum order is fixed and the result bitwise      */
+                          /*   reproducible                                   */
   double lambda0;         /* mass coefficient                                 */
   double lambda1;         /* stiffness coefficient                            */
+  double* dot_out;        /* apply: NULL, or SFEM_DOT_SLOTS device doubles    */
+                          /*   that accumulate partial sums of u . out (the   */
+                          /*   p.Ap of CG, cg.py:78, for free in the scatter) */
 } sfem_helmholtz_args;
+#define SFEM_DOT_SLOTS 1024
 
 int sfem_helmholtz_apply(const sfem_helmholtz_args* args, sfem_stream_t stream);
 
@@ -229,7 +242,10 @@ int sfem_helmholtz_local(const sfem_helmholtz_args* args, sfem_stream_t stream);
  * sfem_dot:            *result  = sum a*b          (clears result first)
  * sfem_dot_accumulate: *result += sum a*b
  * sfem_cg_scalars:     phase 2 = init (after b.b and gamma0 are in place),
- *                      phase 0 = after p.Ap, phase 1 = end of iteration
+ *                      phase 0 = after p.Ap, phase 1 = end of iteration,
+ *                      phase 3 = p.Ap <- sum of the SFEM_DOT_SLOTS partial
+ *                      sums written by sfem_helmholtz_apply (`partials`);
+ *                      phases 1 and 2 clear `partials` when it is given
  * sfem_cg_update_xr:   x += alpha p; r -= alpha Ap;  (cg.py:80-81)
  *                      fuse_rr != 0 also accumulates gamma_new += r.r (M = I)
  * sfem_cg_update_p:    p = z + beta p                (cg.py:84-85)          */
@@ -239,7 +255,7 @@ int sfem_dot(const void* a, const void* b, int64_t count, double* result,
 int sfem_dot_accumulate(const void* a, const void* b, int64_t count,
                         double* result, int dtype, sfem_stream_t stream);
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
-                    double atol, sfem_stream_t stream);
+                    double atol, double* partials, sfem_stream_t stream);
 int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,
                       int64_t count, double* scalars, int fuse_rr, int dtype,
                       sfem_stream_t stream);

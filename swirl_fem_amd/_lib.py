@@ -16,6 +16,7 @@ ABI_VERSION = 1
 
 SFEM_F32, SFEM_F64 = 0, 1
 SFEM_CG_NSCALARS = 16
+SFEM_DOT_SLOTS = 1024
 
 c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_void_p)
@@ -30,7 +31,8 @@ class HelmholtzArgs(ctypes.Structure):
       ('num_elements', c_i64), ('num_listed', c_i64), ('num_nodes', c_i64),
       ('zero_begin', c_i64), ('zero_end', c_i64), ('ndim', c_i32),
       ('P', c_i32), ('ncomp', c_i32), ('dtype', c_i32), ('geo_mode', c_i32),
-      ('reserved', c_i32), ('lambda0', c_dbl), ('lambda1', c_dbl),
+      ('colored', c_i32), ('lambda0', c_dbl), ('lambda1', c_dbl),
+      ('dot_out', c_ptr),
   ]
 
 
@@ -57,14 +59,14 @@ SIGNATURES = {
                           c_ptr],
     'sfem_helmholtz_setup': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
                              c_i32, c_ptr],
-    'sfem_encode_elements': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
+    'sfem_encode_elements': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr],
     'sfem_helmholtz_apply': [ctypes.POINTER(HelmholtzArgs), c_ptr],
     'sfem_helmholtz_setup_multilinear': [c_ptr, c_ptr, c_i64, c_i32, c_i32,
                                          c_i32, c_ptr],
     'sfem_helmholtz_local': [ctypes.POINTER(HelmholtzArgs), c_ptr],
     'sfem_dot': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_dot_accumulate': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
-    'sfem_cg_scalars': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr],
+    'sfem_cg_scalars': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr, c_ptr],
     'sfem_cg_update_xr': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32,
                           c_i32, c_ptr],
     'sfem_cg_update_p': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],

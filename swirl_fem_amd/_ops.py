@@ -227,14 +227,15 @@ def helmholtz_setup(invjac, jacdet, weights_nd):
   return geo
 
 
-def encode_elements(elements, dirichlet_u8, multiplicity):
+def encode_elements(elements, dirichlet_u8, multiplicity, slot_shared=None):
   elements = _idx(elements)
-  dev = _dev(elements, dirichlet_u8, multiplicity)
+  dev = _dev(elements, dirichlet_u8, multiplicity, slot_shared)
   enc = torch.empty_like(elements)
   with torch.cuda.device(dev):
     _lib.check(_lib.load().sfem_encode_elements(
-        _ptr(elements), _ptr(dirichlet_u8), _ptr(multiplicity), _ptr(enc),
-        elements.numel(), _stream(dev)), 'sfem_encode_elements')
+        _ptr(elements), _ptr(dirichlet_u8), _ptr(multiplicity),
+        _ptr(slot_shared), _ptr(enc), elements.numel(), _stream(dev)),
+        'sfem_encode_elements')
   return enc
 
 
@@ -266,7 +267,7 @@ def _dptr(t):
 
 
 def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
-                    lambda0, lambda1, zero_range):
+                    lambda0, lambda1, zero_range, dot_out=None):
   """Builds `sfem_helmholtz_args`; `part` = dict(geo_mode, geo, geo_elem,
   geo_index, elem_list), `host` = dict(dmat, weights, nodes) NumPy arrays
   (kept alive by the caller for the duration of the call)."""
@@ -281,11 +282,13 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       num_listed=0 if lst is None else lst.numel(), num_nodes=num_nodes,
       zero_begin=int(zero_range[0]), zero_end=int(zero_range[1]), ndim=ndim,
       P=P, ncomp=ncomp, dtype=_dtype_code(u), geo_mode=part['geo_mode'],
-      reserved=0, lambda0=float(lambda0), lambda1=float(lambda1))
+      colored=int(bool(part.get('colored', False))), lambda0=float(lambda0),
+      lambda1=float(lambda1),
+      dot_out=_dptr(dot_out))
 
 
 def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
-                    zero_range):
+                    zero_range, dot_out=None):
   """out <- mask * scatter((l0 B + l1 A)_local(gather(u))).
 
   `parts`: one dict per geometry kind present in the mesh (see
@@ -296,9 +299,9 @@ def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
   host = {k: _host(v, u.dtype) for k, v in host.items()}
   with torch.cuda.device(dev):
     for n, part in enumerate(parts):
-      args = _helmholtz_args(u, out, enc, part, host, ndim, P, enc.shape[0],
-                             u.shape[0], lambda0, lambda1,
-                             zero_range if n == 0 else (0, 0))
+      args = _helmholtz_args(u, out, part.get('enc', enc), part, host, ndim,
+                             P, enc.shape[0], u.shape[0], lambda0, lambda1,
+                             zero_range if n == 0 else (0, 0), dot_out)
       _lib.check(_lib.load().sfem_helmholtz_apply(ctypes.byref(args),
                                                   _stream(dev)),
                  'sfem_helmholtz_apply')
@@ -332,12 +335,12 @@ def dot(a, b, result, slot, accumulate=False):
                   _dtype_code(a), _stream(dev)), 'sfem_dot')
 
 
-def cg_scalars(scalars, phase, maxiter, tol, atol):
-  dev = _dev(scalars)
+def cg_scalars(scalars, phase, maxiter, tol, atol, partials=None):
+  dev = _dev(scalars, partials)
   with torch.cuda.device(dev):
     _lib.check(_lib.load().sfem_cg_scalars(
         _ptr(scalars), phase, float(maxiter), float(tol), float(atol),
-        _stream(dev)), 'sfem_cg_scalars')
+        _ptr(partials), _stream(dev)), 'sfem_cg_scalars')
 
 
 def cg_update_xr(x, r, p, ap, scalars, fuse_rr):

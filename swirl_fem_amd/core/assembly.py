@@ -36,6 +36,74 @@ class AssemblyPlan:
     return cls(multiplicity=mult, zero_range=rng, num_shared=num_shared,
                _mesh=mesh)
 
+  def coloring(self, seed: int = 0):
+    """Conflict-free colour classes of the elements (no two elements of one
+    class share a node) and, per element slot, whether it is the FIRST toucher
+    of its node in colour order.
+
+    Greedy maximal-independent-set colouring with random priorities
+    (Luby / Jones-Plassmann): a class is grown by repeatedly adding the
+    remaining elements that hold the largest priority at every one of their
+    corner nodes and are not adjacent to the class so far.  In a conforming
+    tensor-product mesh two elements that share any node share a corner node,
+    so corners decide adjacency; the result is verified on all shared slots.
+
+    Returns (colors (E,) int32, num_colors, first (E, n) bool).
+    """
+    if 'coloring' in self.__dict__:
+      return self.__dict__['coloring']
+    mesh = self._mesh
+    el = mesh.elements.to(torch.int64)
+    E, n = el.shape
+    d = mesh.ndim
+    P = mesh.gridpoints_1d.num_points
+    N = mesh.num_nodes
+    # corner slots of the lexicographic node lattice
+    idx = torch.arange(n, device=el.device).reshape([P] * d)
+    corner = idx[tuple([[0, P - 1]] * 1)] if d == 1 else idx
+    for ax in range(d):
+      corner = corner.index_select(ax, torch.tensor([0, P - 1],
+                                                    device=el.device))
+    cn = el[:, corner.reshape(-1)]                       # (E, 2^d)
+    valid = cn >= 0
+    cn = torch.where(valid, cn, torch.zeros_like(cn))
+    gen = torch.Generator(device=el.device).manual_seed(seed)
+    prio = (torch.randperm(E, device=el.device, generator=gen) + 1).to(
+        torch.int64)
+    colors = torch.full((E,), -1, dtype=torch.int32, device=el.device)
+    num_colors = 0
+    real = valid.any(dim=1)                              # not a padding element
+    colors[~real] = 0
+    while bool((colors < 0).any()):
+      cand = colors < 0
+      used = torch.zeros(N, dtype=torch.bool, device=el.device)
+      while bool(cand.any()):
+        p = torch.where(cand, prio, torch.zeros_like(prio))
+        node_max = torch.zeros(N, dtype=torch.int64, device=el.device)
+        node_max.scatter_reduce_(0, cn.reshape(-1),
+                                 p[:, None].expand_as(cn).reshape(-1), 'amax')
+        sel = cand & ((node_max[cn] == p[:, None]) | ~valid).all(dim=1)
+        colors[sel] = num_colors
+        used[cn[sel].reshape(-1)] = True
+        cand = cand & ~sel & ~(used[cn] & valid).any(dim=1)
+      num_colors += 1
+    num_colors = max(num_colors, 1)
+    # first toucher of every node = the slot whose element has the least colour
+    slot_color = colors.to(torch.int64)[:, None].expand(E, n)
+    ok = el >= 0
+    node_min = torch.full((N,), num_colors, dtype=torch.int64,
+                          device=el.device)
+    node_min.scatter_reduce_(0, el[ok], slot_color[ok], 'amin')
+    first = ok & (node_min[torch.where(ok, el, torch.zeros_like(el))] ==
+                  slot_color)
+    # verification on every slot: a node is touched at most once per colour
+    key = el[ok] * num_colors + slot_color[ok]
+    if key.numel() and int(torch.bincount(key).max()) > 1:
+      raise RuntimeError('element colouring has a node conflict '
+                         '(non-conforming mesh?)')
+    self.__dict__['coloring'] = (colors, num_colors, first)
+    return self.__dict__['coloring']
+
   def csr(self):
     """(offsets (N+1,) int64, slots (nnz,) int32), slots ascending per node."""
     if self._csr is None:

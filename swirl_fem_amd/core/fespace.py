@@ -306,7 +306,8 @@ class FiniteElementSpace:
     return out.reshape((E, self.mesh.num_nodes_per_element) + value_shape)
 
   # -------------------------------------------------------- fused operators
-  def helmholtz_operator(self, dirichlet_mask=None, geometry='auto'):
+  def helmholtz_operator(self, dirichlet_mask=None, geometry='auto',
+                         assembly='atomic'):
     """Fused `out = mask * scatter((l0 B + l1 A)_local(gather(u)))`.
 
     `geometry`: 'auto' evaluates the geometric factors of affine / multilinear
@@ -316,10 +317,10 @@ class FiniteElementSpace:
     """
     from swirl_fem_amd.core import operators
     key = ('helmholtz', None if dirichlet_mask is None else id(dirichlet_mask),
-           geometry)
+           geometry, assembly)
     if key not in self._cache:
       self._cache[key] = operators.HelmholtzOperator.create(
-          self, dirichlet_mask, geometry)
+          self, dirichlet_mask, geometry, assembly)
     return self._cache[key]
 
 

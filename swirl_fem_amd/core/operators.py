@@ -93,8 +93,8 @@ class HelmholtzOperator:
   num_curved: int = 0
 
   @classmethod
-  def create(cls, fespace, dirichlet_mask=None,
-             geometry='auto') -> 'HelmholtzOperator':
+  def create(cls, fespace, dirichlet_mask=None, geometry='auto',
+             assembly='atomic') -> 'HelmholtzOperator':
     """geometry: 'auto' (per element: affine / multilinear / stored factors),
     'multilinear' (no affine shortcut) or 'stored' (6 factors per point for
     every element, the general-geometry path)."""
@@ -103,6 +103,8 @@ class HelmholtzOperator:
       raise NotImplementedError(f'fused Helmholtz kernel unavailable: {why}')
     if geometry not in ('auto', 'multilinear', 'stored'):
       raise ValueError(f'unknown geometry mode {geometry!r}')
+    if assembly not in ('atomic', 'colored'):
+      raise ValueError(f'unknown assembly mode {assembly!r}')
     mesh = fespace.mesh
     E = mesh.num_elements
     w = torch.as_tensor(fespace.quadrature.weights_nd(mesh.ndim),
@@ -145,19 +147,47 @@ class HelmholtzOperator:
       mask = torch.as_tensor(dirichlet_mask, device=fespace.device)
       mask = (mask != 0).to(torch.uint8).contiguous()
     enc = _ops.encode_elements(mesh.elements, mask, plan.multiplicity)
+    zero_range = plan.zero_range
+    if assembly == 'colored':
+      # One launch per (geometry kind, colour class): elements of a class share
+      # no node, shared slots read-modify-write `out` in colour order (no
+      # atomics, no zero-fill of the shared range, bitwise reproducible).
+      colors, num_colors, first = plan.coloring()
+      slot_shared = ((mesh.elements >= 0) & ~first).to(torch.uint8).contiguous()
+      enc = _ops.encode_elements(mesh.elements, mask, None, slot_shared)
+      colored_parts = []
+      for part in parts:
+        in_part = (torch.ones(E, dtype=torch.bool, device=fespace.device)
+                   if 'elem_list' not in part else None)
+        if in_part is None:
+          in_part = torch.zeros(E, dtype=torch.bool, device=fespace.device)
+          in_part[part['elem_list'].to(torch.int64)] = True
+        for c in range(num_colors):
+          lst = torch.nonzero(in_part & (colors == c)).reshape(-1)
+          if lst.numel():
+            colored_parts.append(dict(
+                part, elem_list=lst.to(torch.int32).contiguous(),
+                colored=True))
+      parts = colored_parts
+      unref = torch.nonzero(plan.multiplicity == 0).reshape(-1)
+      zero_range = ((int(unref.min()), int(unref.max()) + 1)
+                    if unref.numel() else (0, 0))
     host = {'dmat': fespace.interpolator._differentiation_matrix_1d(),
             'weights': np.asarray(fespace.quadrature.weights),
             'nodes': np.asarray(mesh.gridpoints_1d.node_values)}
     return cls(fespace=fespace, parts=parts, enc=enc, host=host,
-               zero_range=plan.zero_range, num_affine=counts[_GEO_AFFINE],
+               zero_range=zero_range, num_affine=counts[_GEO_AFFINE],
                num_multilinear=counts[_GEO_MULTILINEAR],
                num_curved=counts[_GEO_POINT])
 
-  def apply(self, u, lambda0=0.0, lambda1=1.0, out=None, *, zero=True):
+  def apply(self, u, lambda0=0.0, lambda1=1.0, out=None, *, zero=True,
+            dot_out=None):
     """u (N,) or (N, nc) -> mask * scatter((l0 B + l1 A)_local(gather(u))).
 
     `zero=False` skips clearing the shared-node range of `out` (the caller has
-    cleared it; used by bench.py to time the kernel alone).
+    cleared it; used by bench.py to time the kernel alone).  `dot_out`: a
+    device tensor of `_lib.SFEM_DOT_SLOTS` doubles that accumulates partial
+    sums of `u . out` (CG's p.Ap for free inside the scatter stage).
     """
     mesh = self.fespace.mesh
     if u.shape[0] != mesh.num_nodes:
@@ -169,7 +199,7 @@ class HelmholtzOperator:
     return _ops.helmholtz_apply(
         u, out, self.enc, self.parts, self.host, mesh.ndim,
         mesh.gridpoints_1d.num_points, lambda0, lambda1,
-        self.zero_range if zero else (0, 0))
+        self.zero_range if zero else (0, 0), dot_out)
 
   def apply_local(self, u_local, lambda0=0.0, lambda1=1.0):
     """Element-local action (E, n[, nc]) -> (E, n[, nc]); no gather/scatter."""
@@ -177,3 +207,22 @@ class HelmholtzOperator:
     return _ops.helmholtz_local(
         u_local.to(self.fespace.dtype), self.parts, self.host, mesh.ndim,
         mesh.gridpoints_1d.num_points, lambda0, lambda1)
+
+  def linear_operator(self, lambda0=0.0, lambda1=1.0):
+    """`u -> apply(u, lambda0, lambda1)` as an object that `cg` recognises:
+    it also offers `apply_with_dot(u, partials)` (fused p.Ap)."""
+    return FusedLinearOperator(self, lambda0, lambda1)
+
+
+class FusedLinearOperator:
+  """Callable operator with a fused `u . A(u)` for `linalg.cg.cg`."""
+
+  def __init__(self, op, lambda0, lambda1):
+    self.op, self.lambda0, self.lambda1 = op, lambda0, lambda1
+
+  def __call__(self, u):
+    return self.op.apply(u, self.lambda0, self.lambda1)
+
+  def apply_with_dot(self, u, partials):
+    """Returns A(u) and accumulates partial sums of u . A(u)."""
+    return self.op.apply(u, self.lambda0, self.lambda1, dot_out=partials)

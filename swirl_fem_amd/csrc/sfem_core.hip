@@ -282,8 +282,20 @@ cg_update_p_kernel(T* __restrict__ p, const T* __restrict__ z, int64_t count,
 // phase 1 (gamma_new accumulated in [2]): beta = gamma_new / gamma;
 //     gamma <- gamma_new; clear pAp; ++iterations;
 //     done <- !(gamma > atol2) or iterations >= maxiter   (cg.py:68-73)
-__global__ void cg_scalar_kernel(double* scalars, int phase, double maxiter,
-                                 double tol, double atol) {
+__global__ void __launch_bounds__(256)
+cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
+                 double atol, double* partials) {
+  const int tid = threadIdx.x;
+  if (phase == 3) {           // p.Ap <- sum of the fused partial sums
+    double v = 0.0;
+    for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) v += partials[q];
+    const double total = block_sum(v);
+    if (tid == 0 && scalars[7] == 0.0) scalars[1] = total;
+    return;
+  }
+  if (partials && (phase == 1 || phase == 2))
+    for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) partials[q] = 0.0;
+  if (tid != 0) return;
   if (phase == 2) {
     const double a = tol * tol * scalars[5], b = atol * atol;
     scalars[6] = a > b ? a : b;
@@ -525,11 +537,12 @@ int sfem_cg_update_p(void* p, const void* z, int64_t count, double* scalars,
 }
 
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
-                    double atol, sfem_stream_t stream) {
-  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 2,
+                    double atol, double* partials, sfem_stream_t stream) {
+  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 3 && (phase != 3 || partials),
                "sfem_cg_scalars: bad arguments");
-  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(1), 0, as_stream(stream),
-                     scalars, phase, maxiter, tol, atol);
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
+                     as_stream(stream), scalars, phase, maxiter, tol, atol,
+                     partials);
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

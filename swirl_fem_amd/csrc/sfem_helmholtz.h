@@ -58,6 +58,9 @@ struct HelmholtzParams {
   int comp;              // first component
   T lambda0, lambda1;
   int debug_flags;       // reserved for A/B experiments (SFEM_DEBUG_FLAGS)
+  double* dot_out;       // SFEM_DOT_SLOTS partial sums of u . out, or null
+  int colored;           // launches are conflict-free colour classes: SHARED
+                         // slots read-modify-write instead of atomics
 };
 
 __host__ __device__ constexpr int round_up(int a, int b) {
@@ -89,7 +92,7 @@ struct HelmholtzTile {
   static constexpr int BLOCK = round_up(EPB * TPE, 64);
   // register budget: ask for >= MINW waves per SIMD (latency hiding for an
   // HBM-bound kernel); larger lines need more registers per lane.
-  static constexpr int MINW = (P * (int)sizeof(T) <= 64) ? 4 : 2;
+  static constexpr int MINW = P <= 8 ? 4 : 2;
   static constexpr int NGEO = DIM == 3 ? 6 : (DIM == 2 ? 3 : 1);
 };
 
@@ -455,12 +458,21 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   const T* ug = prm.u + prm.comp;
   T* og = prm.out + prm.comp;
 
+  double udot = 0.0;   // this lane's share of u . out (fused p.Ap of CG)
   for (int k = 0; k < nc; ++k) {
     if (!SCALAR) {
       // keep address arithmetic, flag tests and geometry products inside the
       // component loop: hoisted out of it they occupy ~100 registers and spill
       asm volatile("" : "+v"(geom.lane_off), "+v"(slot_off_v));
       if (GM != GEO_POINT) asm volatile("" : "+v"(geom.wbc));
+      if (GM == GEO_MULTILINEAR) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          asm volatile("" : "+v"(geom.r0[c]), "+v"(geom.p1[c]),
+                       "+v"(geom.q1[c]));
+          if (DIM == 3) asm volatile("" : "+v"(geom.p2[c]), "+v"(geom.q2[c]));
+        }
+      }
     }
     T ua[P], acc[P];
 #pragma unroll
@@ -590,8 +602,12 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         if (id != SFEM_IDX_PAD) {
           T* dst = og + (int64_t)id * cs + k;
           const bool dirichlet = ea & SFEM_IDX_DIRICHLET;
+          if (!dirichlet) udot += (double)acc[a] * (double)ua[a];
           if (ea & SFEM_IDX_SHARED) {
-            if (!dirichlet) unsafeAtomicAdd(dst, acc[a]);
+            if (!dirichlet) {
+              if (prm.colored) *dst = *dst + acc[a];
+              else unsafeAtomicAdd(dst, acc[a]);
+            }
           } else {
             *dst = dirichlet ? T(0) : acc[a];
           }
@@ -601,6 +617,16 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
       }
     }
     if (k + 1 < nc) __syncthreads();
+  }
+  if (GS && prm.dot_out) {
+    // u . out = sum over element slots of u_slot * (local result)_slot: one
+    // wave reduction and one atomic per wave into a strip of partial sums
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
+    if ((tid & 63) == 0)
+      unsafeAtomicAdd(&prm.dot_out[(blockIdx.x * (Tile::BLOCK / 64) +
+                                    (tid >> 6)) & (SFEM_DOT_SLOTS - 1)],
+                      udot);
   }
 }
 
@@ -629,14 +655,7 @@ int launch_helmholtz(const HelmholtzParams<T>& prm, hipStream_t stream) {
   } else if (prm.geo_mode == GEO_AFFINE) {
     SFEM_LAUNCH_GM(false, GEO_AFFINE, prm);
   } else {
-    // on-the-fly geometry: one single-component launch per component keeps
-    // the kernel inside its register budget (no per-point data is re-read)
-    for (int k = 0; k < prm.ncomp; ++k) {
-      HelmholtzParams<T> one = prm;
-      one.ncomp = 1;
-      one.comp = prm.comp + k;
-      SFEM_LAUNCH_GM(true, GEO_MULTILINEAR, one);
-    }
+    SFEM_LAUNCH_GM(false, GEO_MULTILINEAR, prm);
   }
 #undef SFEM_LAUNCH_GM
   SFEM_LAUNCH_CHECK();

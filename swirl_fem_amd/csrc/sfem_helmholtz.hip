@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(256)
 encode_kernel(const int32_t* __restrict__ elements,
               const uint8_t* __restrict__ dirichlet,
               const int32_t* __restrict__ multiplicity,
+              const uint8_t* __restrict__ slot_shared,
               int32_t* __restrict__ enc, int64_t count) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
@@ -60,7 +61,8 @@ encode_kernel(const int32_t* __restrict__ elements,
     } else {
       v = (uint32_t)k;
       if (dirichlet && dirichlet[k]) v |= SFEM_IDX_DIRICHLET;
-      if (multiplicity[k] > 1) v |= SFEM_IDX_SHARED;
+      if (slot_shared ? slot_shared[i] != 0 : multiplicity[k] > 1)
+        v |= SFEM_IDX_SHARED;
     }
     enc[i] = (int32_t)v;
   }
@@ -116,6 +118,8 @@ struct HelmholtzCall {
   const void* geo_elem; const int32_t* geo_index; const int32_t* elem_list;
   const void* dmat; const void* weights; const void* nodes;
   int64_t num_elements; int ndim, P, ncomp, geo_mode; double l0, l1; bool gs;
+  double* dot_out;
+  int colored;
 };
 
 template <typename T>
@@ -129,6 +133,8 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
   prm.elem_list = c.elem_list; prm.ncomp = c.ncomp; prm.comp_stride = c.ncomp;
   prm.comp = 0; prm.lambda0 = (T)c.l0; prm.lambda1 = (T)c.l1;
   prm.debug_flags = 0;
+  prm.dot_out = c.dot_out;
+  prm.colored = c.colored;
   if (c.ndim == 3) return dispatch_helmholtz<T, 3>(prm, c.P, c.gs, stream);
   if (c.ndim == 2) return dispatch_helmholtz<T, 2>(prm, c.P, c.gs, stream);
   set_error("helmholtz: ndim=%d (fused kernel supports 2 and 3)", c.ndim);
@@ -186,15 +192,16 @@ int sfem_helmholtz_setup(const void* invjac, const void* jacdet,
 }
 
 int sfem_encode_elements(const int32_t* elements, const uint8_t* dirichlet,
-                         const int32_t* multiplicity, int32_t* enc,
+                         const int32_t* multiplicity,
+                         const uint8_t* slot_shared, int32_t* enc,
                          int64_t count, sfem_stream_t stream) {
   SFEM_REQUIRE(count >= 0, "sfem_encode_elements: negative count");
   if (count == 0) return SFEM_OK;
-  SFEM_REQUIRE(elements && multiplicity && enc,
+  SFEM_REQUIRE(elements && (multiplicity || slot_shared) && enc,
                "sfem_encode_elements: null pointer");
   hipLaunchKernelGGL(encode_kernel, dim3(stream_grid(count, 256)), dim3(256), 0,
-                     as_stream(stream), elements, dirichlet, multiplicity, enc,
-                     count);
+                     as_stream(stream), elements, dirichlet, multiplicity,
+                     slot_shared, enc, count);
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }
@@ -230,7 +237,8 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   if (work == 0) return SFEM_OK;
   HelmholtzCall c{a->u, a->out, a->enc, a->geo, a->geo_elem, a->geo_index,
                   a->elem_list, a->dmat, a->weights, a->nodes, work, a->ndim,
-                  a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, true};
+                  a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, true,
+                  a->dot_out, a->colored};
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
 }
@@ -280,7 +288,8 @@ int sfem_helmholtz_local(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   if (work == 0) return SFEM_OK;
   HelmholtzCall c{a->u, a->out, nullptr, a->geo, a->geo_elem, a->geo_index,
                   a->elem_list, a->dmat, a->weights, a->nodes, work, a->ndim,
-                  a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, false};
+                  a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, false,
+                  nullptr, 0};
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
 }

@@ -57,6 +57,9 @@ class _Scalars:
   def __init__(self, device):
     self.t = torch.zeros(_lib.SFEM_CG_NSCALARS, dtype=torch.float64,
                          device=device)
+    # strip of partial sums for operators that fuse p.Ap into their scatter
+    self.partials = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
+                                device=device)
 
   def dot_into(self, slot, a, b, dot_fn, reduce_fn):
     """scalars[slot] = <a, b> summed over the leaves of the pytrees."""
@@ -104,7 +107,11 @@ class CGRunner:
     z = self.r if self.identity_m else M(self.r)
     self.p = _map(lambda t: t.clone().contiguous(), z)
     s.dot_into(S.GAMMA, self.r, z, dot_fn, reduce_fn)
-    _ops.cg_scalars(s.t, 2, maxiter, tol, atol)
+    # operators exposing `apply_with_dot` hand back p.Ap with the apply
+    self.fused_dot = (dot_fn is None and hasattr(A, 'apply_with_dot') and
+                      isinstance(self.p, torch.Tensor))
+    self.parts = s.partials if self.fused_dot else None
+    _ops.cg_scalars(s.t, 2, maxiter, tol, atol, self.parts)
     self.fuse_rr = self.identity_m and dot_fn is None and reduce_fn is None
     self.issued = 0
 
@@ -112,9 +119,17 @@ class CGRunner:
     """One iteration of cg.py:75-86, all on the device."""
     s, S = self.s, _Scalars
     A, M, dot_fn, reduce_fn = self.A, self.M, self.dot_fn, self.reduce_fn
-    args = (self.maxiter, self.tol, self.atol)
-    Ap = A(self.p)
-    if dot_fn is None:
+    args = (self.maxiter, self.tol, self.atol, self.parts)
+    if self.fused_dot:
+      Ap = A.apply_with_dot(self.p, s.partials)
+      _ops.cg_scalars(s.t, 3, *args)
+      if reduce_fn is not None:
+        reduce_fn(s.t[S.PAP:S.PAP + 1])
+    else:
+      Ap = A(self.p)
+    if self.fused_dot:
+      pass
+    elif dot_fn is None:
       # slot PAP is zero here: cleared by phase 2 / phase 1
       for xx, yy in zip(_leaves(self.p), _leaves(Ap)):
         _ops.dot(xx.reshape(-1), yy.contiguous().reshape(-1), s.t, S.PAP,

@@ -504,6 +504,40 @@ def test_cg_matches_oracle_iterates():
   assert ig['num_iterations'] == 0 and float(xg.abs().max()) == 0.0
 
 
+def test_cg_with_fused_operator_dot():
+  """The operator's in-kernel u.A(u) equals the separate dot; CG iterates and
+  iteration counts with it match the oracle's CG on the same operator."""
+  from swirl_fem_amd import _lib
+  from swirl_fem_amd.linalg.cg import cg
+  for ndim, n, P in [(3, 3, 4), (2, 5, 6), (3, 2, 8)]:
+    rp = make_case(ndim, n, P, seed=21)
+    mesh, fes, ofes = spaces(rp, P, P, 'gll')
+    bmask = mesh.physical_masks['boundary'].cpu().numpy()
+    op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
+    rng = np.random.default_rng(22)
+    for nc in (1, ndim):
+      u = rng.standard_normal((mesh.num_nodes, nc))
+      uu = u[:, 0] if nc == 1 else u
+      parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64, device=DEV)
+      Au = op.apply(dev(uu), 0.3, 1.0, dot_out=parts)
+      ref = _helmholtz_ref(ofes, uu, 0.3, 1.0, bmask)
+      assert relerr(Au, ref) < 1e-10
+      assert float(parts.sum()) == pytest.approx(float(np.vdot(uu, ref)),
+                                                 rel=1e-11)
+    interior = 1.0 - bmask
+    b = interior * rng.standard_normal(mesh.num_nodes)
+    A = op.linear_operator(0.2, 1.0)
+    assert relerr(A(dev(b)), _helmholtz_ref(ofes, b, 0.2, 1.0, bmask)) < 1e-10
+    for tol in (1e-6, 1e-12):
+      xo, io = O.cg(lambda x: _helmholtz_ref(ofes, x, 0.2, 1.0, bmask), b,
+                    tol=tol)
+      xg, ig = cg(A, dev(b), tol=tol, check_every=7)
+      assert ig['num_iterations'] == io['num_iterations']
+      assert relerr(xg, xo) < 1e-8
+      xs, is_ = cg(lambda x: op.apply(x, 0.2, 1.0), dev(b), tol=tol)
+      assert is_['num_iterations'] == io['num_iterations']
+
+
 # ------------------------------------------------------------------ Poisson
 def test_poisson_config1_matches_oracle_and_series():
   """BASELINE config 1: 2D Poisson, 16x16 quads on [-1,1]^2, p=3."""
