@@ -41,6 +41,16 @@ for rep in range(2):
 for g, o in ops.items():
   timeit(f'helmholtz geometry={g}', lambda o=o: o.apply(u, 0.7, 1.0, out=out, zero=False))
   timeit(f'mass geometry={g}', lambda o=o: o.apply(u, 1.0, 0.0, out=out, zero=False))
+import time
+t0 = time.time(); opc = fes.helmholtz_operator(bm, 'auto', 'colored'); torch.cuda.synchronize()
+print('colouring setup s', time.time() - t0, 'launches', len(opc.parts), 'colors', mesh.assembly_plan().coloring()[1])
+ops['auto-colored'] = opc
+for rep in range(2):
+  timeit('apply auto colored', lambda: opc.apply(u, 0.0, 1.0, out=out))
+  timeit('apply auto atomic', lambda: ops['auto'].apply(u, 0.0, 1.0, out=out))
+opsc = fes.helmholtz_operator(bm, 'stored', 'colored')
+timeit('apply stored colored', lambda: opsc.apply(u, 0.0, 1.0, out=out))
+timeit('apply stored atomic', lambda: ops['stored'].apply(u, 0.0, 1.0, out=out))
 u3 = torch.randn(mesh.num_nodes, 3, dtype=torch.float64, device=dev)
 o3 = torch.empty_like(u3)
 for g, o in ops.items():

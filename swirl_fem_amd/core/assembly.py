@@ -50,8 +50,8 @@ class AssemblyPlan:
 
     Returns (colors (E,) int32, num_colors, first (E, n) bool).
     """
-    if 'coloring' in self.__dict__:
-      return self.__dict__['coloring']
+    if '_coloring_cache' in self.__dict__:
+      return self.__dict__['_coloring_cache']
     mesh = self._mesh
     el = mesh.elements.to(torch.int64)
     E, n = el.shape
@@ -101,8 +101,8 @@ class AssemblyPlan:
     if key.numel() and int(torch.bincount(key).max()) > 1:
       raise RuntimeError('element colouring has a node conflict '
                          '(non-conforming mesh?)')
-    self.__dict__['coloring'] = (colors, num_colors, first)
-    return self.__dict__['coloring']
+    self.__dict__['_coloring_cache'] = (colors, num_colors, first)
+    return self.__dict__['_coloring_cache']
 
   def csr(self):
     """(offsets (N+1,) int64, slots (nnz,) int32), slots ascending per node."""

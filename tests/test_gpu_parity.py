@@ -437,6 +437,54 @@ def test_fused_helmholtz_geometry_kinds(ndim, n, P, dtype):
                     ofes.mass_local(ul)) < tol, (mode, g)
 
 
+@pytest.mark.parametrize('ndim,n,P,scramble', [(3, 4, 4, False), (3, 3, 5, True),
+                                               (2, 6, 4, True), (3, 2, 8, False)])
+def test_fused_helmholtz_colored_assembly(ndim, n, P, scramble):
+  """One launch per conflict-free colour class: same operator, no atomics,
+  bitwise reproducible."""
+  rp = make_case(ndim, n, P, seed=23, scramble=scramble)
+  mesh, fes, ofes = spaces(rp, P, P, 'gll')
+  bmask = mesh.physical_masks['boundary'].cpu().numpy()
+  plan = mesh.assembly_plan()
+  colors, ncol, first = plan.coloring()
+  assert 2 ** ndim <= ncol <= 4 * 2 ** ndim
+  # every node has exactly one first toucher; classes are conflict free
+  el = mesh.elements.to(torch.int64)
+  cnt = torch.zeros(mesh.num_nodes, dtype=torch.int64, device=DEV)
+  cnt.index_add_(0, el[first], torch.ones_like(el[first]))
+  assert int(cnt.min()) == 1 and int(cnt.max()) == 1
+  for c in range(ncol):
+    nodes = el[colors == c].reshape(-1)
+    assert nodes.unique().numel() == nodes.numel()
+  rng = np.random.default_rng(24)
+  for geometry in ('auto', 'stored'):
+    op_c = fes.helmholtz_operator(mesh.physical_masks['boundary'], geometry,
+                                  'colored')
+    op_a = fes.helmholtz_operator(mesh.physical_masks['boundary'], geometry,
+                                  'atomic')
+    for nc in (1, 3):
+      u = rng.standard_normal((mesh.num_nodes, nc))
+      uu = u[:, 0] if nc == 1 else u
+      ref = _helmholtz_ref(ofes, uu, 0.6, 1.2, bmask)
+      # poison the output buffer: every entry must be written
+      out = torch.full_like(dev(uu), float('nan'))
+      got = op_c.apply(dev(uu), 0.6, 1.2, out=out)
+      assert relerr(got, ref) < 1e-10
+      again = op_c.apply(dev(uu), 0.6, 1.2)
+      assert torch.equal(got, again)
+      assert relerr(op_a.apply(dev(uu), 0.6, 1.2), ref) < 1e-10
+  # CG with the coloured operator (fused dot) matches the oracle
+  from swirl_fem_amd.linalg.cg import cg
+  b = (1.0 - bmask) * rng.standard_normal(mesh.num_nodes)
+  op_c = fes.helmholtz_operator(mesh.physical_masks['boundary'], 'auto',
+                                'colored')
+  xo, io = O.cg(lambda x: _helmholtz_ref(ofes, x, 0.1, 1.0, bmask), b,
+                tol=1e-10)
+  xg, ig = cg(op_c.linear_operator(0.1, 1.0), dev(b), tol=1e-10)
+  assert ig['num_iterations'] == io['num_iterations']
+  assert relerr(xg, xo) < 1e-8
+
+
 def test_fused_helmholtz_padded_elements_and_errors():
   # partition-style padding: trailing elements with all -1 connectivity
   rp = make_case(3, 2, 4, seed=15)
