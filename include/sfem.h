@@ -215,6 +215,11 @@ typedef struct sfem_helmholtz_args {
                           /*   reproducible                                   */
   double lambda0;         /* mass coefficient                                 */
   double lambda1;         /* stiffness coefficient                            */
+  int64_t node_stride;    /* layout of u / out in elements: entry (node, k) at*/
+  int64_t comp_stride;    /*   node*node_stride + k*comp_stride.  0, 0 = the  */
+                          /*   default (N, ncomp) row-major layout; (1, N) =  */
+                          /*   component-major storage seen as an (N, ncomp)  */
+                          /*   view, which keeps every component contiguous   */
   double* dot_out;        /* apply: NULL, or SFEM_DOT_SLOTS device doubles    */
                           /*   that accumulate partial sums of u . out (the   */
                           /*   p.Ap of CG, cg.py:78, for free in the scatter) */

@@ -55,6 +55,10 @@ u3 = torch.randn(mesh.num_nodes, 3, dtype=torch.float64, device=dev)
 o3 = torch.empty_like(u3)
 for g, o in ops.items():
   ms = timeit(f'3-component stiffness geometry={g}', lambda o=o: o.apply(u3, 0.0, 1.0, out=o3, zero=False))
+ucm = torch.randn(3, mesh.num_nodes, dtype=torch.float64, device=dev).t()
+ocm = torch.empty_like(ucm)
+for g in ('auto', 'stored'):
+  timeit(f'3-component, component-major, geometry={g}', lambda o=ops[g]: o.apply(ucm, 0.0, 1.0, out=ocm, zero=False))
 a = torch.empty(mesh.num_nodes * 10, dtype=torch.float64, device=dev)
 b = torch.empty_like(a)
 ms = timeit('torch copy 7.2GB+7.2GB', lambda: b.copy_(a))

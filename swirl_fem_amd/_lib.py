@@ -32,7 +32,7 @@ class HelmholtzArgs(ctypes.Structure):
       ('zero_begin', c_i64), ('zero_end', c_i64), ('ndim', c_i32),
       ('P', c_i32), ('ncomp', c_i32), ('dtype', c_i32), ('geo_mode', c_i32),
       ('colored', c_i32), ('lambda0', c_dbl), ('lambda1', c_dbl),
-      ('dot_out', c_ptr),
+      ('node_stride', c_i64), ('comp_stride', c_i64), ('dot_out', c_ptr),
   ]
 
 

@@ -70,8 +70,18 @@ def gather(u, indices, fill):
 
 
 def gather_rows(x, indices):
-  """x (N, nc), indices (...) -> (..., nc); SENTINEL rows are zero."""
+  """x (N, nc), indices (...) -> (..., nc); SENTINEL rows are zero.
+
+  A component-major `x` gives a component-major result (one scalar gather per
+  contiguous component strip)."""
   indices = _idx(indices)
+  if is_component_major(x):
+    from swirl_fem_amd.core import layout
+    out = layout.empty_component_major(tuple(indices.shape) + (x.shape[-1],),
+                                       x.dtype, x.device)
+    for k in range(x.shape[-1]):
+      out[..., k].copy_(gather(x[:, k], indices, 0.0))
+    return out
   x = x.contiguous()
   dev = _dev(x, indices)
   nc = x.shape[-1]
@@ -85,6 +95,13 @@ def gather_rows(x, indices):
 
 def scatter_add(u_local, indices, num_nodes, ncomp=1):
   indices = _idx(indices)
+  if ncomp > 1 and is_component_major(u_local):
+    from swirl_fem_amd.core import layout
+    out = layout.empty_component_major((num_nodes, ncomp), u_local.dtype,
+                                       u_local.device)
+    for k in range(ncomp):
+      out[:, k].copy_(scatter_add(u_local[..., k], indices, num_nodes))
+    return out
   u_local = u_local.contiguous()
   dev = _dev(u_local, indices)
   shape = (num_nodes,) if ncomp == 1 and u_local.dim() == indices.dim() else (
@@ -114,6 +131,11 @@ _unique_cache = {}
 
 def exchange_local(u, gather_indices, unique_indices):
   """Unpartitioned QQ^T; `unique_indices` is a host array (static)."""
+  if is_component_major(u):
+    out = torch.empty_like(u)
+    for k in range(u.shape[-1]):
+      out[:, k].copy_(exchange_local(u[:, k], gather_indices, unique_indices))
+    return out
   u = u.contiguous()
   gidx = _idx(gather_indices)
   dev = _dev(u, gidx)
@@ -271,7 +293,13 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
   """Builds `sfem_helmholtz_args`; `part` = dict(geo_mode, geo, geo_elem,
   geo_index, elem_list), `host` = dict(dmat, weights, nodes) NumPy arrays
   (kept alive by the caller for the duration of the call)."""
-  ncomp = 1 if u.dim() == (1 if enc is not None else 2) else u.shape[-1]
+  vec = u.dim() != (1 if enc is not None else 2)
+  ncomp = u.shape[-1] if vec else 1
+  node_stride = comp_stride = 0
+  if vec and not u.is_contiguous():
+    # component-major storage viewed as (..., ncomp): every component is a
+    # contiguous strip
+    node_stride, comp_stride = 1, u.stride(-1)
   lst = part.get('elem_list')
   return _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),
@@ -283,7 +311,8 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       zero_begin=int(zero_range[0]), zero_end=int(zero_range[1]), ndim=ndim,
       P=P, ncomp=ncomp, dtype=_dtype_code(u), geo_mode=part['geo_mode'],
       colored=int(bool(part.get('colored', False))), lambda0=float(lambda0),
-      lambda1=float(lambda1),
+      lambda1=float(lambda1), node_stride=node_stride,
+      comp_stride=comp_stride,
       dot_out=_dptr(dot_out))
 
 
@@ -295,7 +324,8 @@ def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
   `_helmholtz_args`); the shared-node range of `out` is cleared by the first
   launch only.
   """
-  dev = _dev(u, out, enc)
+  dev = _dev(enc)
+  _check_vector_layout(u, out)
   host = {k: _host(v, u.dtype) for k, v in host.items()}
   with torch.cuda.device(dev):
     for n, part in enumerate(parts):
@@ -308,11 +338,28 @@ def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
   return out
 
 
+from swirl_fem_amd.core.layout import is_component_major  # noqa: E402
+
+
+def _check_vector_layout(u, out):
+  for t in (u, out):
+    if not t.is_cuda:
+      raise RuntimeError(
+          'swirl_fem_amd kernels run on MI355X device tensors only; got a '
+          f'{t.device} tensor (there is no CPU fallback)')
+    if not (t.is_contiguous() or is_component_major(t)):
+      raise ValueError('expected a contiguous or component-major tensor')
+  if u.stride() != out.stride() or u.shape != out.shape:
+    raise ValueError('u and out must share shape and memory layout')
+
+
 def helmholtz_local(u_local, parts, host, ndim, P, lambda0, lambda1):
-  u_local = u_local.contiguous()
-  dev = _dev(u_local)
+  if not (u_local.is_contiguous() or is_component_major(u_local)):
+    u_local = u_local.contiguous()
+  dev = u_local.device
   host = {k: _host(v, u_local.dtype) for k, v in host.items()}
-  out = torch.empty_like(u_local)
+  out = torch.empty_like(u_local)       # preserves the (dense) layout
+  _check_vector_layout(u_local, out)
   with torch.cuda.device(dev):
     for part in parts:
       args = _helmholtz_args(u_local, out, None, part, host, ndim, P,

@@ -193,9 +193,11 @@ class HelmholtzOperator:
     if u.shape[0] != mesh.num_nodes:
       raise ValueError(f'expected {mesh.num_nodes} nodal values, got '
                        f'{tuple(u.shape)}')
-    u = u.to(self.fespace.dtype).contiguous()
+    u = u.to(self.fespace.dtype)
+    if not (u.is_contiguous() or _ops.is_component_major(u)):
+      u = u.contiguous()
     if out is None:
-      out = torch.empty_like(u)
+      out = torch.empty_like(u)        # same (dense) memory layout as u
     return _ops.helmholtz_apply(
         u, out, self.enc, self.parts, self.host, mesh.ndim,
         mesh.gridpoints_1d.num_points, lambda0, lambda1,

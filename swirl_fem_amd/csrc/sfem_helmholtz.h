@@ -54,7 +54,8 @@ struct HelmholtzParams {
   int64_t num_elements;  // elements processed by this launch
   const int32_t* elem_list;  // their ids, or null = 0..num_elements-1
   int ncomp;             // components handled inside the kernel
-  int comp_stride;       // stride between nodes of u / out (>= ncomp)
+  int64_t node_stride;   // u / out: element offset = node * node_stride +
+  int64_t comp_stride;   //                           component * comp_stride
   int comp;              // first component
   T lambda0, lambda1;
   int debug_flags;       // reserved for A/B experiments (SFEM_DEBUG_FLAGS)
@@ -433,7 +434,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   // SCALAR: one component known at compile time (no component loop, so the
   // compiler has nothing to hoist out of it and spill)
   const int nc = SCALAR ? 1 : prm.ncomp;
-  const int cs = prm.comp_stride;
+  const int64_t ns = prm.node_stride, ks = prm.comp_stride;
   const bool has_mass = prm.lambda0 != T(0);
   const bool has_stiff = prm.lambda1 != T(0);
 
@@ -453,10 +454,10 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
       enc[a] = active ? (uint32_t)enc0[slot_off + a * TPE]
                       : (uint32_t)SFEM_IDX_PAD;
   }
-  const T* ul0 = GS ? nullptr : prm.u + e * N * cs + prm.comp;
-  T* ol0 = GS ? nullptr : prm.out + e * N * cs + prm.comp;
-  const T* ug = prm.u + prm.comp;
-  T* og = prm.out + prm.comp;
+  const T* ul0 = GS ? nullptr : prm.u + e * N * ns + prm.comp * ks;
+  T* ol0 = GS ? nullptr : prm.out + e * N * ns + prm.comp * ks;
+  const T* ug = prm.u + prm.comp * ks;
+  T* og = prm.out + prm.comp * ks;
 
   double udot = 0.0;   // this lane's share of u . out (fused p.Ap of CG)
   for (int k = 0; k < nc; ++k) {
@@ -479,9 +480,9 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
     for (int a = 0; a < P; ++a) {
       if (GS) {
         const uint32_t id = enc[a] & SFEM_IDX_MASK;
-        ua[a] = id == SFEM_IDX_PAD ? T(0) : ug[(int64_t)id * cs + k];
+        ua[a] = id == SFEM_IDX_PAD ? T(0) : ug[(int64_t)id * ns + k * ks];
       } else {
-        ua[a] = active ? ul0[(slot_off + a * TPE) * cs + k] : T(0);
+        ua[a] = active ? ul0[(int64_t)(slot_off + a * TPE) * ns + k * ks] : T(0);
       }
     }
     if (has_stiff) {
@@ -600,7 +601,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         asm volatile("" : "+v"(ea));
         const uint32_t id = ea & SFEM_IDX_MASK;
         if (id != SFEM_IDX_PAD) {
-          T* dst = og + (int64_t)id * cs + k;
+          T* dst = og + (int64_t)id * ns + k * ks;
           const bool dirichlet = ea & SFEM_IDX_DIRICHLET;
           if (!dirichlet) udot += (double)acc[a] * (double)ua[a];
           if (ea & SFEM_IDX_SHARED) {
@@ -613,7 +614,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
           }
         }
       } else if (active) {
-        ol0[(slot_off + a * TPE) * cs + k] = acc[a];
+        ol0[(int64_t)(slot_off + a * TPE) * ns + k * ks] = acc[a];
       }
     }
     if (k + 1 < nc) __syncthreads();

@@ -120,6 +120,7 @@ struct HelmholtzCall {
   int64_t num_elements; int ndim, P, ncomp, geo_mode; double l0, l1; bool gs;
   double* dot_out;
   int colored;
+  int64_t node_stride, comp_stride;
 };
 
 template <typename T>
@@ -130,7 +131,9 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
   prm.geo_index = c.geo_index; prm.geo_mode = c.geo_mode;
   prm.dmat_host = (const T*)c.dmat; prm.weights_host = (const T*)c.weights;
   prm.nodes_host = (const T*)c.nodes; prm.num_elements = c.num_elements;
-  prm.elem_list = c.elem_list; prm.ncomp = c.ncomp; prm.comp_stride = c.ncomp;
+  prm.elem_list = c.elem_list; prm.ncomp = c.ncomp;
+  prm.node_stride = c.node_stride > 0 ? c.node_stride : c.ncomp;
+  prm.comp_stride = c.node_stride > 0 ? c.comp_stride : 1;
   prm.comp = 0; prm.lambda0 = (T)c.l0; prm.lambda1 = (T)c.l1;
   prm.debug_flags = 0;
   prm.dot_out = c.dot_out;
@@ -221,11 +224,24 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   if (a->num_nodes == 0) return SFEM_OK;
   SFEM_REQUIRE(a->out, "sfem_helmholtz_apply: null out");
   const size_t esz = a->dtype == SFEM_F64 ? 8 : 4;
-  if (a->zero_end > a->zero_begin)
-    SFEM_HIP(hipMemsetAsync(
-        (char*)a->out + (size_t)a->zero_begin * a->ncomp * esz, 0,
-        (size_t)(a->zero_end - a->zero_begin) * a->ncomp * esz,
-        as_stream(stream)));
+  if (a->zero_end > a->zero_begin) {
+    if (a->node_stride > 0 && a->node_stride != a->ncomp) {
+      // component-major layout: one contiguous strip per component
+      SFEM_REQUIRE(a->node_stride == 1,
+                   "sfem_helmholtz_apply: unsupported vector layout");
+      for (int k = 0; k < a->ncomp; ++k)
+        SFEM_HIP(hipMemsetAsync(
+            (char*)a->out +
+                ((size_t)k * a->comp_stride + a->zero_begin) * esz,
+            0, (size_t)(a->zero_end - a->zero_begin) * esz,
+            as_stream(stream)));
+    } else {
+      SFEM_HIP(hipMemsetAsync(
+          (char*)a->out + (size_t)a->zero_begin * a->ncomp * esz, 0,
+          (size_t)(a->zero_end - a->zero_begin) * a->ncomp * esz,
+          as_stream(stream)));
+    }
+  }
   if (a->num_elements == 0) return SFEM_OK;
   SFEM_REQUIRE(a->u && a->enc && a->dmat, "sfem_helmholtz_apply: null pointer");
   int rc = check_geometry("sfem_helmholtz_apply", a->geo_mode, a->geo,
@@ -238,7 +254,7 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   HelmholtzCall c{a->u, a->out, a->enc, a->geo, a->geo_elem, a->geo_index,
                   a->elem_list, a->dmat, a->weights, a->nodes, work, a->ndim,
                   a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, true,
-                  a->dot_out, a->colored};
+                  a->dot_out, a->colored, a->node_stride, a->comp_stride};
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
 }
@@ -289,7 +305,7 @@ int sfem_helmholtz_local(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   HelmholtzCall c{a->u, a->out, nullptr, a->geo, a->geo_elem, a->geo_index,
                   a->elem_list, a->dmat, a->weights, a->nodes, work, a->ndim,
                   a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, false,
-                  nullptr, 0};
+                  nullptr, 0, a->node_stride, a->comp_stride};
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
 }

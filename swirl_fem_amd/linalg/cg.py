@@ -25,6 +25,7 @@ import torch
 
 from swirl_fem_amd import _lib
 from swirl_fem_amd import _ops
+from swirl_fem_amd.core import layout
 
 
 def _leaves(t):
@@ -67,7 +68,7 @@ class _Scalars:
     if dot_fn is None:
       first = True
       for x, y in zip(la, lb):
-        _ops.dot(x.reshape(-1), y.reshape(-1), self.t, slot,
+        _ops.dot(layout.flat(x), layout.flat(layout.like(y, x)), self.t, slot,
                  accumulate=not first)
         first = False
     else:
@@ -97,15 +98,18 @@ class CGRunner:
       maxiter = 10 * sum(l.numel() for l in b_leaves)
     self.maxiter = maxiter
     device = b_leaves[0].device
+    dense = lambda t: t if (t.is_contiguous() or
+                            layout.is_component_major(t)) else t.contiguous()
+    b = _map(dense, b)
     self.x = (_map(torch.zeros_like, b) if x0 is None
-              else _map(lambda t: t.contiguous().clone(), x0))
+              else _map(lambda t, bb: layout.like(t, bb).clone(), x0, b))
     self.s = s = _Scalars(device)
     S = _Scalars
     self.identity_m = M is None
     s.dot_into(S.BB, b, b, dot_fn, reduce_fn)
-    self.r = _map(lambda bb, ax: (bb - ax).contiguous(), b, A(self.x))
+    self.r = _map(lambda bb, ax: bb - layout.like(ax, bb), b, A(self.x))
     z = self.r if self.identity_m else M(self.r)
-    self.p = _map(lambda t: t.clone().contiguous(), z)
+    self.p = _map(lambda t, rr: layout.like(t, rr).clone(), z, self.r)
     s.dot_into(S.GAMMA, self.r, z, dot_fn, reduce_fn)
     # operators exposing `apply_with_dot` hand back p.Ap with the apply
     self.fused_dot = (dot_fn is None and hasattr(A, 'apply_with_dot') and
@@ -132,8 +136,8 @@ class CGRunner:
     elif dot_fn is None:
       # slot PAP is zero here: cleared by phase 2 / phase 1
       for xx, yy in zip(_leaves(self.p), _leaves(Ap)):
-        _ops.dot(xx.reshape(-1), yy.contiguous().reshape(-1), s.t, S.PAP,
-                 accumulate=True)
+        _ops.dot(layout.flat(xx), layout.flat(layout.like(yy, xx)), s.t,
+                 S.PAP, accumulate=True)
       if reduce_fn is not None:
         reduce_fn(s.t[S.PAP:S.PAP + 1])
     else:
@@ -141,15 +145,15 @@ class CGRunner:
     _ops.cg_scalars(s.t, 0, *args)
     for xx, rr, pp, aa in zip(_leaves(self.x), _leaves(self.r),
                               _leaves(self.p), _leaves(Ap)):
-      _ops.cg_update_xr(xx.reshape(-1), rr.reshape(-1), pp.reshape(-1),
-                        aa.contiguous().reshape(-1), s.t, self.fuse_rr)
+      _ops.cg_update_xr(layout.flat(xx), layout.flat(rr), layout.flat(pp),
+                        layout.flat(layout.like(aa, xx)), s.t, self.fuse_rr)
     if self.fuse_rr:
       z = self.r
     else:
       z = self.r if self.identity_m else M(self.r)
       if dot_fn is None:
         for xx, yy in zip(_leaves(self.r), _leaves(z)):
-          _ops.dot(xx.reshape(-1), yy.contiguous().reshape(-1), s.t,
+          _ops.dot(layout.flat(xx), layout.flat(layout.like(yy, xx)), s.t,
                    S.GAMMA_NEW, accumulate=True)
         if reduce_fn is not None:
           reduce_fn(s.t[S.GAMMA_NEW:S.GAMMA_NEW + 1])
@@ -157,7 +161,7 @@ class CGRunner:
         # after convergence the done flag guards every consumer of this slot
         s.dot_into(S.GAMMA_NEW, self.r, z, dot_fn, reduce_fn)
     for pp, zz in zip(_leaves(self.p), _leaves(z)):
-      _ops.cg_update_p(pp.reshape(-1), zz.contiguous().reshape(-1), s.t)
+      _ops.cg_update_p(layout.flat(pp), layout.flat(layout.like(zz, pp)), s.t)
     _ops.cg_scalars(s.t, 1, *args)
     self.issued += 1
 

@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 from swirl_fem_amd.core import basis
+from swirl_fem_amd.core import layout
 from swirl_fem_amd.core import operators
 from swirl_fem_amd.core.fespace import div
 from swirl_fem_amd.core.fespace import FiniteElementSpace
@@ -201,8 +202,9 @@ class StokesVelocity:
     if mesh.axis_name is None:
       if mesh.exchange_unique_indices is None:
         return u.clone()
-      return _ops.exchange_local(u.contiguous(), gi,
-                                 mesh.exchange_unique_indices)
+      if not layout.is_component_major(u):
+        u = u.contiguous()
+      return _ops.exchange_local(u, gi, mesh.exchange_unique_indices)
     from swirl_fem_amd.distributed import comm
     return comm.neighbor_exchange(u.contiguous(), mesh.neighbor_plan)
 
@@ -382,6 +384,9 @@ class StokesSEM:
     if u_boundary is not None:
       f = f - H_(u_boundary)
 
+    # component-major storage for the Helmholtz solve: every kernel of the CG
+    # then works on contiguous component strips (same (N, d) shape for callers)
+    f = layout.component_major(f)
     u_star, info = cg(H_, f, M=self.velocity.exchange, tol=tol, atol=atol)
     if u_boundary is not None:
       u_star = u_star + u_boundary

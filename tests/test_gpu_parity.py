@@ -379,6 +379,16 @@ def test_fused_helmholtz_fp32_and_vector(ndim, n, P):
       ul = rng.standard_normal(rp.elements.shape + (ndim,))
       got = op.apply_local(dev(ul, dtype), 0.0, 1.0)
       assert relerr(got, ofes.stiffness_local(ul)) < tol
+      # component-major storage seen as (N, nc) / (E, n, nc) views
+      u = rng.standard_normal((mesh.num_nodes, 3))
+      ucm = dev(u.T.copy(), dtype).t()
+      assert not ucm.is_contiguous() and ucm.shape == (mesh.num_nodes, 3)
+      got = op.apply(ucm, 0.5, 1.5)
+      assert got.stride() == ucm.stride()
+      assert relerr(got, _helmholtz_ref(ofes, u, 0.5, 1.5, bmask)) < tol
+      ulcm = dev(np.moveaxis(ul, -1, 0).copy(), dtype).movedim(0, -1)
+      got = op.apply_local(ulcm, 0.0, 1.0)
+      assert relerr(got, ofes.stiffness_local(ul)) < tol
 
 
 @pytest.mark.parametrize('ndim,n,P', [(2, 4, 5), (3, 3, 4), (3, 3, 8)])
