@@ -108,6 +108,9 @@ def main():
                   help="'auto': affine / multilinear elements evaluate their "
                        "geometric factors in registers; 'stored': 6 factors "
                        "per point are read for every element")
+  ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
+  ap.add_argument('--mass-coeff', type=float, default=0.0,
+                  help='Helmholtz operator mass_coeff * B + A (0 = Laplacian)')
   ap.add_argument('--jitter', type=float, default=0.0,
                   help='smooth mesh deformation amplitude (fraction of h)')
   args = ap.parse_args()
@@ -135,8 +138,11 @@ def main():
   grid = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
   t_setup = time.perf_counter()
   from swirl_fem_amd.distributed import blocks
+  tdtype = torch.float64 if args.dtype == 'f64' else torch.float32
+  sizeof = 8 if args.dtype == 'f64' else 4
   part = blocks.build_block_partition(args.n, P, block_grid(world), rank,
-                                      device=device, jitter=args.jitter)
+                                      device=device, jitter=args.jitter,
+                                      dtype=tdtype)
   mesh = part.mesh
   fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
   op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
@@ -148,7 +154,7 @@ def main():
   N_global = part.num_global_nodes
 
   g = torch.Generator(device=device).manual_seed(1234 + rank)
-  b = torch.randn(N_local, dtype=torch.float64, device=device, generator=g)
+  b = torch.randn(N_local, dtype=tdtype, device=device, generator=g)
   if 'boundary' in mesh.physical_masks:
     b = b * (~mesh.physical_masks['boundary']).to(b.dtype)
   # Partitioned CG follows the reference's solver convention
@@ -158,7 +164,7 @@ def main():
   out_buf = torch.empty_like(b)
 
   # the operator also hands CG its p.Ap (accumulated in the scatter stage)
-  A = op.linear_operator(0.0, 1.0)
+  A = op.linear_operator(args.mass_coeff, 1.0)
 
   if world > 1:
     run = CGRunner(A, b, tol=0.0, atol=0.0, maxiter=10 ** 9, M=mesh.exchange,
@@ -194,13 +200,13 @@ def main():
          torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
   from swirl_fem_amd import _ops
   for _ in range(3):
-    op.apply(u, 0.0, 1.0, out=out_buf)
+    op.apply(u, args.mass_coeff, 1.0, out=out_buf)
   torch.cuda.synchronize()
   for s0, s1 in ev:
     if hi > lo:
       out_buf[lo:hi].zero_()                 # outside the event pair
     s0.record()
-    op.apply(u, 0.0, 1.0, out=out_buf, zero=False)
+    op.apply(u, args.mass_coeff, 1.0, out=out_buf, zero=False)
     s1.record()
   torch.cuda.synchronize()
   kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
@@ -209,25 +215,28 @@ def main():
       enable_timing=True)
   s0.record()
   for _ in range(args.steps):
-    op.apply(u, 0.0, 1.0, out=out_buf)
+    op.apply(u, args.mass_coeff, 1.0, out=out_buf)
   s1.record()
   torch.cuda.synchronize()
   apply_ms = s0.elapsed_time(s1) / args.steps
-  alg_bytes = algorithmic_bytes_per_apply(E, n, N_local)
+  alg_bytes = algorithmic_bytes_per_apply(
+      E, n, N_local, sizeof=sizeof, ngeo=7 if args.mass_coeff else 6)
   achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
   if rank == 0:
     res = {
-        'metric': 'GDOF/s per CG iteration, 3D p=%d Laplacian' % args.p,
+        'metric': 'GDOF/s per CG iteration, 3D p=%d %s' % (
+            args.p, 'Helmholtz' if args.mass_coeff else 'Laplacian'),
         'value': value, 'unit': 'GDOF/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
         'data': 'synthetic',
         'config': {
-            'workload': '3D Laplacian CG iteration, %d^3 hex elements per GPU, '
-                        'p=%d GLL collocated, fp64, Dirichlet' % (args.n,
-                                                                  args.p),
+            'workload': '3D %s CG iteration, %d^3 hex elements per GPU, '
+                        'p=%d GLL collocated, %s, Dirichlet' % (
+                            'Helmholtz' if args.mass_coeff else 'Laplacian',
+                            args.n, args.p, args.dtype),
             'elements_per_gpu': E, 'dofs_global': N_global,
             'blocks': 'x'.join(map(str, block_grid(world))),
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
@@ -241,7 +250,8 @@ def main():
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-            'kernel': 'sfem::helmholtz_kernel<double, %d, 3, true, true, GM>' % P,
+            'kernel': 'sfem::helmholtz_kernel<%s, %d, 3, true, true, GM>' % (
+                'double' if args.dtype == 'f64' else 'float', P),
             'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg_bytes,
             'note': ('algorithmic bytes are the stored-6-factor model of '
                      'SURVEY 8(d) for every element; affine / multilinear '

@@ -69,9 +69,11 @@ def classify_geometry(fespace):
   recon = centre + torch.einsum('nm,emd->end', mono, A)
   size = lin.abs().amax(dim=(1, 2))
   err = (recon - xe).abs().amax(dim=(1, 2))
-  multi = err <= MULTILINEAR_RTOL[xe.dtype] * size
+  # coordinates carry rounding of their own magnitude (matters in fp32)
+  noise = 8 * torch.finfo(xe.dtype).eps * xe.abs().amax(dim=(1, 2))
+  multi = err <= MULTILINEAR_RTOL[xe.dtype] * size + noise
   affine = multi & (nonlin.abs().amax(dim=(1, 2)) <=
-                    AFFINE_RTOL[xe.dtype] * size)
+                    AFFINE_RTOL[xe.dtype] * size + noise)
   kind = torch.zeros(xe.shape[0], dtype=torch.int32, device=xe.device)
   kind[multi] = _GEO_MULTILINEAR
   kind[affine] = _GEO_AFFINE
