@@ -136,3 +136,74 @@ def test_stokes_one_step(case):
       0, 1, DT, K, alpha=0.05, tol=1e-12, atol=1e-12)
   assert relerr(u, uo) < 1e-8
   assert np.abs(pr.cpu().numpy() - po).max() < 1e-7
+
+
+# --------------------------------------------- drivers (BASELINE configs 3, 4)
+def _staged(pm, order):
+  return SC.staged_meshes(pm, order)
+
+
+def test_lid_driven_cavity_steps_match_oracle():
+  """Config 3 in small: 2D cavity, unstructured (jittered, permuted) quads,
+  p=5, BDF3/EXT2, lid through u_boundary; three steps vs the oracle."""
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.examples import navier_stokes_driver as drv
+  rng = np.random.default_rng(3)
+  n, order = 4, 5
+  pm = unit_cube_mesh(n, ndim=2)
+  x = pm.node_coords.copy()
+  inner = np.all((x > 1e-9) & (x < 1 - 1e-9), axis=1)
+  x[inner] += 0.2 / n * rng.uniform(-1, 1, (int(inner.sum()), 2))
+  pm = pm.replace(node_coords=x,
+                  elements=pm.elements[rng.permutation(pm.num_elements)])
+  sem, u, p, diag = drv.lid_driven_cavity(order=order, reynolds=100.0, dt=1e-3,
+                                          steps=3, device=DEV, premesh=pm,
+                                          tol=1e-11)
+  v, pp = _staged(pm, order)
+  orc = O.StokesOracle(v, pp, order, v['physical_masks']['boundary'])
+  xc = v['node_coords']
+  lid = (xc[:, 1] > 1 - 1e-12).astype(float)
+  ub = np.stack([lid * 16 * xc[:, 0] ** 2 * (1 - xc[:, 0]) ** 2,
+                 np.zeros(len(xc))], axis=-1)
+  us = (ub,) * 3
+  ps = (np.zeros(len(pp['node_coords'])),) * 3
+  Cus = (orc.C(ub),) * 3
+  for _ in range(3):
+    uo, po, Co, _ = O.navier_stokes_step(orc, us, ps, Cus, 100.0, 1e-3, 3,
+                                         u_boundary=ub, tol=1e-11, atol=0.0)
+    us, ps, Cus = us[1:] + (uo,), ps[1:] + (po,), Cus[1:] + (Co,)
+  assert relerr(u, us[-1]) < 1e-7
+  assert np.abs(p.cpu().numpy() - ps[-1]).max() < 1e-6 * max(
+      1.0, np.abs(ps[-1]).max())
+  # the lid value is kept on the boundary, the flow is discretely solenoidal
+  bmask = v['physical_masks']['boundary']
+  assert np.abs(u.cpu().numpy()[bmask] - ub[bmask]).max() < 1e-12
+  assert diag['max_divergence'] < 1e-6
+
+
+def test_taylor_green_3d_periodic():
+  """Config 4 in small: 3D triply periodic box, operators vs the oracle and a
+  few time steps (energy decays, divergence stays small)."""
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.examples import navier_stokes_driver as drv
+  n, order = 3, 3
+  sem, u, p, diag = drv.taylor_green(n=n, order=order, reynolds=50.0, dt=2e-2,
+                                     steps=3, device=DEV, tol=1e-10)
+  e = diag['kinetic_energy']
+  assert all(b < a for a, b in zip(e, e[1:]))
+  assert e[-1] > 0.8 * e[0]
+  assert diag['max_divergence'] < 1e-6
+  pm = unit_cube_mesh(n, ndim=3, a=0.0, b=2 * np.pi, periodic_dims=(0, 1, 2))
+  v, pp = _staged(pm, order)
+  orc = O.StokesOracle(v, pp, order, np.zeros(len(v['node_coords']), bool))
+  rng = np.random.default_rng(4)
+  w = rng.standard_normal((len(v['node_coords']), 3))
+  q = rng.standard_normal(len(pp['node_coords']))
+  assert relerr(sem.A(dev(w)), orc.A(w)) < 1e-10
+  assert relerr(sem.C(dev(w)), orc.C(w)) < 1e-10
+  assert relerr(sem.D(dev(w)), orc.D(w)) < 1e-10
+  assert relerr(sem.Dt(dev(q)), orc.Dt(q)) < 1e-10
+  assert relerr(sem.Bi(dev(w)), orc.Bi(w)) < 1e-12
+  assert relerr(sem.filter(dev(w)), orc.filter(w)) < 1e-11
+  assert relerr(sem.velocity.exchange(dev(w)), orc.vexchange(w)) < 1e-13
+  assert relerr(sem.E(dev(q), 1e-2, 3), orc.E(q, 1e-2, 3)) < 1e-9
