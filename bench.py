@@ -103,6 +103,8 @@ def main():
   ap.add_argument('--n', type=int, default=64, help='elements per dim per GPU')
   ap.add_argument('--p', type=int, default=7, help='polynomial order')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-general', action='store_true',
+                  help='skip timing the stored-factor kernel beside the default')
   ap.add_argument('--geometry', default='auto',
                   choices=['auto', 'multilinear', 'stored'],
                   help="'auto': affine / multilinear elements evaluate their "
@@ -111,6 +113,8 @@ def main():
   ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
   ap.add_argument('--mass-coeff', type=float, default=0.0,
                   help='Helmholtz operator mass_coeff * B + A (0 = Laplacian)')
+  ap.add_argument('--tile', type=int, default=0,
+                  help='visit elements in tile^3 blocks (0 = lexicographic)')
   ap.add_argument('--jitter', type=float, default=0.0,
                   help='smooth mesh deformation amplitude (fraction of h)')
   args = ap.parse_args()
@@ -142,7 +146,7 @@ def main():
   sizeof = 8 if args.dtype == 'f64' else 4
   part = blocks.build_block_partition(args.n, P, block_grid(world), rank,
                                       device=device, jitter=args.jitter,
-                                      dtype=tdtype)
+                                      dtype=tdtype, tile=args.tile)
   mesh = part.mesh
   fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
   op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
@@ -219,6 +223,26 @@ def main():
   s1.record()
   torch.cuda.synchronize()
   apply_ms = s0.elapsed_time(s1) / args.steps
+  # the same mesh through the general-geometry path (6 stored factors per
+  # point are READ): the kernel whose traffic the stored-factor model describes
+  general = None
+  if world == 1 and args.geometry == 'auto' and not args.no_general:
+    op_g = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
+                                  geometry='stored')
+    for _ in range(3):
+      op_g.apply(u, args.mass_coeff, 1.0, out=out_buf)
+    torch.cuda.synchronize()
+    evg = [(torch.cuda.Event(enable_timing=True),
+            torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for s0, s1 in evg:
+      if hi > lo:
+        out_buf[lo:hi].zero_()
+      s0.record()
+      op_g.apply(u, args.mass_coeff, 1.0, out=out_buf, zero=False)
+      s1.record()
+    torch.cuda.synchronize()
+    general = float(np.mean([a.elapsed_time(b_) for a, b_ in evg]))
+    del op_g
   alg_bytes = algorithmic_bytes_per_apply(
       E, n, N_local, sizeof=sizeof, ngeo=7 if args.mass_coeff else 6)
   achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -259,6 +283,14 @@ def main():
                      'recomputed in registers, not read)'),
         },
     }
+    if general is not None:
+      res['roofline_stored_factors'] = {
+          'bound': 'hbm', 'achieved': alg_bytes / (general * 1e-3) / 1e9,
+          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+          'frac': alg_bytes / (general * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          'kernel_ms': general,
+          'kernel': 'same launch with geometry=stored (GM=0): every element '
+                    'reads its 6 factors per point, as curved elements do'}
     if world == 1 and not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(P)
     else:

@@ -9,7 +9,7 @@ from swirl_fem_amd import _ops
 
 n = int(os.environ.get('N', '64')); P = int(os.environ.get('P', '8'))
 dev = torch.device('cuda:0')
-part = blocks.build_block_partition(n, P, (1, 1, 1), 0, device=dev, jitter=float(os.environ.get('JITTER', '0')))
+part = blocks.build_block_partition(n, P, (1, 1, 1), 0, device=dev, jitter=float(os.environ.get('JITTER', '0')), tile=int(os.environ.get('TILE', '0')))
 mesh = part.mesh
 grid = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
 fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
