@@ -38,6 +38,20 @@ def algorithmic_bytes_per_apply(E, n, N, sizeof=8, ngeo=6):
   return 4 * E * n + sizeof * N + ngeo * sizeof * E * n + sizeof * N
 
 
+def measured_traffic(n, p, dtype, geometry, jitter):
+  """HBM bytes per launch of the dominant kernel measured with rocprofv3 PMC
+  counters for this exact workload (profiles/traffic_r01.json), or None."""
+  key = 'n%d_p%d_%s_%s' % (n, p, dtype, 'stored' if geometry == 'stored'
+                           else 'auto')
+  path = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
+  try:
+    with open(path) as f:
+      entry = json.load(f).get(key)
+  except (OSError, ValueError):
+    return None
+  return None if entry is None else entry['bytes']
+
+
 def block_grid(world):
   return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(
       world, (world, 1, 1))
@@ -273,7 +287,13 @@ def main():
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': measured_traffic(args.n, args.p, args.dtype,
+                                        args.geometry, args.jitter),
+            'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+                              'of this command (profiles/traffic_r01.json, '
+                              'profiles/r01_pmc_notes.md); null if this '
+                              'workload was not profiled',
             'kernel': 'sfem::helmholtz_kernel<%s, %d, 3, true, true, GM>' % (
                 'double' if args.dtype == 'f64' else 'float', P),
             'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg_bytes,
