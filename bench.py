@@ -114,7 +114,7 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=50)
   ap.add_argument('--warmup', type=int, default=10)
-  ap.add_argument('--n', type=int, default=64, help='elements per dim per GPU')
+  ap.add_argument('--n', '--elems', dest='n', type=int, default=64, help='elements per dim per GPU')
   ap.add_argument('--p', type=int, default=7, help='polynomial order')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-general', action='store_true',
@@ -129,6 +129,14 @@ def main():
                   help='Helmholtz operator mass_coeff * B + A (0 = Laplacian)')
   ap.add_argument('--tile', type=int, default=0,
                   help='visit elements in tile^3 blocks (0 = lexicographic)')
+  ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                  help="'gloo' rehearses the N>1 path with all ranks on the "
+                       'visible GPU(s) (interface buffers staged via host)')
+  ap.add_argument('--partitioned', default='consistent',
+                  choices=['consistent', 'reference'],
+                  help="N>1 CG formulation: consistent vectors with the "
+                       "exchange inside A (default) or the reference's "
+                       'unassembled A with M = exchange')
   ap.add_argument('--jitter', type=float, default=0.0,
                   help='smooth mesh deformation amplitude (fraction of h)')
   args = ap.parse_args()
@@ -145,12 +153,17 @@ def main():
   if world != args.gpus:
     if world == 1 and args.gpus > 1:
       raise SystemExit('launch N>1 with torch.distributed.run (see docstring)')
+  if args.backend == 'gloo':
+    local_rank %= torch.cuda.device_count()
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=device)
+    if args.backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world,
+                              device_id=device)
+    else:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
 
   P = args.p + 1
   grid = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
@@ -184,7 +197,13 @@ def main():
   # the operator also hands CG its p.Ap (accumulated in the scatter stage)
   A = op.linear_operator(args.mass_coeff, 1.0)
 
-  if world > 1:
+  if world > 1 and args.partitioned == 'consistent':
+    # consistent vectors: exchange inside A on the interface nodes only, fused
+    # p.Ap, interface-corrected r.r (distributed/solver.py)
+    from swirl_fem_amd.distributed import solver
+    run = solver.make_runner(A, b, part.plan, tol=0.0, atol=0.0,
+                             maxiter=10 ** 9)
+  elif world > 1:
     run = CGRunner(A, b, tol=0.0, atol=0.0, maxiter=10 ** 9, M=mesh.exchange,
                    reduce_fn=part.reduce_sum_)
   else:
@@ -277,6 +296,9 @@ def main():
                             args.n, args.p, args.dtype),
             'elements_per_gpu': E, 'dofs_global': N_global,
             'blocks': 'x'.join(map(str, block_grid(world))),
+            'partitioned_cg': args.partitioned if world > 1 else None,
+            'backend': ('rccl' if args.backend == 'nccl' else 'gloo '
+                        '(rehearsal)') if world > 1 else None,
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
             'apply_ms': apply_ms, 'setup_s': setup_s,
             'geometry': ('%s: %d affine + %d multilinear elements (factors '

@@ -107,6 +107,18 @@ int sfem_pack(const void* u, const int32_t* idx, void* buf, int64_t count,
 int sfem_unpack_add(const void* buf, const int32_t* idx, void* u,
                     int64_t count, int ncomp, int dtype, sfem_stream_t stream);
 
+/* Single-launch forms for a whole partition interface: `u` is an (N, ncomp)
+ * view with element strides (node_stride, comp_stride) -- row-major or
+ * component-major -- and `idx` is the concatenation of all per-neighbour lists,
+ * so a node may occur several times: the unpack adds atomically.             */
+int sfem_pack_strided(const void* u, const int32_t* idx, void* buf,
+                      int64_t count, int ncomp, int64_t node_stride,
+                      int64_t comp_stride, int dtype, sfem_stream_t stream);
+int sfem_unpack_add_atomic(const void* buf, const int32_t* idx, void* u,
+                           int64_t count, int ncomp, int64_t node_stride,
+                           int64_t comp_stride, int dtype,
+                           sfem_stream_t stream);
+
 /* ------------------------------------------------------ geometric factors ---
  * From element node coordinates (E, n, ndim) computes, per quadrature point,
  *   jac[i][j]  = d x_j / d xi_i      (core/fespace.py:338, via I1/G1 factors)

@@ -50,6 +50,10 @@ SIGNATURES = {
                             c_i64, c_i32, c_i32, c_ptr],
     'sfem_pack': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     'sfem_unpack_add': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
+    'sfem_pack_strided': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64,
+                          c_i32, c_ptr],
+    'sfem_unpack_add_atomic': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64,
+                               c_i64, c_i32, c_ptr],
     'sfem_geom_factors': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32,
                           c_ptr, c_ptr, c_ptr, c_i32, c_ptr],
     'sfem_basis_eval': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32,

@@ -182,6 +182,42 @@ def unpack_add(buf, idx, u):
   return u
 
 
+def _node_view(u):
+  """(ncomp, node_stride, comp_stride) of a dense (N,) / (N, nc) field."""
+  if u.dim() == 1:
+    if u.stride(0) != 1:
+      raise ValueError('nodal vector must be dense')
+    return 1, 1, 1
+  if u.dim() != 2 or not (u.is_contiguous() or is_component_major(u)):
+    raise ValueError('field must be (N,), row-major (N, nc) or component-major')
+  return u.shape[1], u.stride(0), u.stride(1)
+
+
+def pack_strided(u, idx, out=None):
+  """buf[i, k] = u[idx[i], k] for any dense field layout (one launch)."""
+  ncomp, ns, cs = _node_view(u)
+  dev = _dev(u.movedim(-1, 0) if is_component_major(u) else u, idx)
+  shape = (idx.numel(),) if u.dim() == 1 else (idx.numel(), ncomp)
+  buf = out if out is not None else torch.empty(shape, dtype=u.dtype,
+                                                device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_pack_strided(
+        _ptr(u), _ptr(idx), _ptr(buf), idx.numel(), ncomp, ns, cs,
+        _dtype_code(u), _stream(dev)), 'sfem_pack_strided')
+  return buf
+
+
+def unpack_add_atomic(buf, idx, u):
+  """In place: u[idx[i], k] += buf[i, k]; idx may repeat nodes."""
+  ncomp, ns, cs = _node_view(u)
+  dev = _dev(buf, idx, u.movedim(-1, 0) if is_component_major(u) else u)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_unpack_add_atomic(
+        _ptr(buf), _ptr(idx), _ptr(u), idx.numel(), ncomp, ns, cs,
+        _dtype_code(u), _stream(dev)), 'sfem_unpack_add_atomic')
+  return u
+
+
 # ------------------------------------------------------------------ geometry
 def geom_factors(elem_coords, interp1, grad1, ndim, P, q, want_quad_coords):
   elem_coords = elem_coords.contiguous()

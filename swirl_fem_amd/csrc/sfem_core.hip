@@ -136,6 +136,43 @@ unpack_add_kernel(const T* __restrict__ buf, const int32_t* __restrict__ idx,
   }
 }
 
+// Strided variants for the single-launch partition exchange: `u` is any
+// (N, ncomp) view (row-major or component-major); `idx` may name a node more
+// than once (edge / corner nodes shared with several neighbours), hence atomics.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_strided_kernel(const T* __restrict__ u, const int32_t* __restrict__ idx,
+                    T* __restrict__ buf, int64_t count, int ncomp,
+                    int64_t node_stride, int64_t comp_stride) {
+  const int64_t total = count * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t i = t / ncomp;
+    const int c = (int)(t - i * ncomp);
+    const int32_t k = idx[i];
+    buf[t] = k >= 0 ? u[(int64_t)k * node_stride + c * comp_stride] : T(0);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+unpack_add_atomic_kernel(const T* __restrict__ buf,
+                         const int32_t* __restrict__ idx, T* __restrict__ u,
+                         int64_t count, int ncomp, int64_t node_stride,
+                         int64_t comp_stride) {
+  const int64_t total = count * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t i = t / ncomp;
+    const int c = (int)(t - i * ncomp);
+    const int32_t k = idx[i];
+    if (k >= 0)
+      unsafeAtomicAdd(&u[(int64_t)k * node_stride + c * comp_stride], buf[t]);
+  }
+}
+
 // ------------------------------------------------------------ CG kernels ---
 // Block-level sum of one double per thread; one atomic per workgroup.
 __device__ inline double block_sum(double v) {
@@ -474,6 +511,35 @@ int sfem_unpack_add(const void* buf, const int32_t* idx, void* u,
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
       unpack_add_kernel<T>, dim3(stream_grid(count * ncomp, 256)), dim3(256),
       0, as_stream(stream), (const T*)buf, idx, (T*)u, count, ncomp));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_pack_strided(const void* u, const int32_t* idx, void* buf,
+                      int64_t count, int ncomp, int64_t node_stride,
+                      int64_t comp_stride, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && ncomp >= 1, "sfem_pack_strided: bad sizes");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(u && idx && buf, "sfem_pack_strided: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      pack_strided_kernel<T>, dim3(stream_grid(count * ncomp, 256)), dim3(256),
+      0, as_stream(stream), (const T*)u, idx, (T*)buf, count, ncomp,
+      node_stride, comp_stride));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_unpack_add_atomic(const void* buf, const int32_t* idx, void* u,
+                           int64_t count, int ncomp, int64_t node_stride,
+                           int64_t comp_stride, int dtype,
+                           sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && ncomp >= 1, "sfem_unpack_add_atomic: bad sizes");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(buf && idx && u, "sfem_unpack_add_atomic: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      unpack_add_atomic_kernel<T>, dim3(stream_grid(count * ncomp, 256)),
+      dim3(256), 0, as_stream(stream), (const T*)buf, idx, (T*)u, count, ncomp,
+      node_stride, comp_stride));
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

@@ -77,15 +77,49 @@ class NeighborPlan:
   def num_shared(self) -> int:
     return int(sum(len(ix) for ix in self.indices))
 
+  def concat_indices(self, device):
+    """All per-neighbour lists back to back (int32, device) + their lengths."""
+    key = ('cat', str(device))
+    if key not in self._dev:
+      cat = (np.concatenate(self.indices) if self.indices
+             else np.zeros(0, np.int32))
+      self._dev[key] = (torch.as_tensor(cat, dtype=torch.int32, device=device),
+                        [len(ix) for ix in self.indices])
+    return self._dev[key]
 
-def exchange_buffers(plan: NeighborPlan, send_bufs, group=None):
+  def interface_weights(self, device):
+    """`(idx, w)`: the interface nodes of this partition (each once, int64) and
+    `w = 1 - 1/m`, m = number of partitions holding the node.  For vectors that
+    are *consistent* (equal on all holders)  sum_ranks (a.b - sum_idx w a b)
+    is the inner product over the unique global nodes."""
+    key = ('w', str(device))
+    if key not in self._dev:
+      cat = (np.concatenate(self.indices) if self.indices
+             else np.zeros(0, np.int32))
+      idx, cnt = np.unique(cat[cat >= 0], return_counts=True)
+      w = 1.0 - 1.0 / (1.0 + cnt)
+      self._dev[key] = (torch.as_tensor(idx, dtype=torch.int64, device=device),
+                        torch.as_tensor(w, dtype=torch.float64, device=device))
+    return self._dev[key]
+
+
+def exchange_buffers(plan: NeighborPlan, send_bufs, group=None,
+                     recv_bufs=None):
   """Sends `send_bufs[i]` to `plan.neighbors[i]` and returns what they sent.
 
   One grouped batch of P2P ops (RCCL: ncclGroupStart ... ncclGroupEnd), so all
   neighbour links are driven concurrently.
   """
-  recv_bufs = [torch.empty_like(b) for b in send_bufs]
+  if recv_bufs is None:
+    recv_bufs = [torch.empty_like(b) for b in send_bufs]
   if not plan.neighbors:
+    return recv_bufs
+  if send_bufs[0].is_cuda and dist.get_backend(group) == 'gloo':
+    # gloo has no device-memory send/recv: single-GPU rehearsals of the
+    # multi-rank path stage the (small) interface buffers through the host.
+    host = exchange_buffers(plan, [b.cpu() for b in send_bufs], group=group)
+    for rb, hb in zip(recv_bufs, host):
+      rb.copy_(hb)
     return recv_bufs
   ops = []
   for q, sb, rb in zip(plan.neighbors, send_bufs, recv_bufs):
@@ -116,6 +150,22 @@ def neighbor_exchange(u: torch.Tensor, plan: NeighborPlan, group=None, *,
   for rb, ix in zip(recv, idx):
     unpack_add_fn(rb, ix, out)
   return out
+
+
+def neighbor_exchange_(u: torch.Tensor, plan: NeighborPlan,
+                       group=None) -> torch.Tensor:
+  """In-place QQ^T on the interface nodes: one pack launch for all neighbours,
+  one grouped send/recv, one atomic unpack-add.  `u` may be (N,), (N, nc)
+  row-major or component-major; interior nodes are not touched (no clone)."""
+  from swirl_fem_amd import _ops
+  if not plan.neighbors:
+    return u
+  cat, sizes = plan.concat_indices(u.device)
+  send = _ops.pack_strided(u, cat)
+  recv = torch.empty_like(send)
+  exchange_buffers(plan, list(torch.split(send, sizes)), group=group,
+                   recv_bufs=list(torch.split(recv, sizes)))
+  return _ops.unpack_add_atomic(recv, cat, u)
 
 
 def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -62,7 +62,26 @@ class _Scalars:
     self.partials = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
                                 device=device)
 
-  def dot_into(self, slot, a, b, dot_fn, reduce_fn):
+  def interface_correction(self, slot, a, b, interface):
+    """scalars[slot] -= sum_interface w a b: turns the plain local dot of two
+    *consistent* vectors into this rank's share of the global inner product
+    (`NeighborPlan.interface_weights`); the interface is O(N^(2/3)) nodes."""
+    idx, w = interface
+    if idx.numel() == 0:
+      return
+    tot = None
+    for x, y in zip(_leaves(a), _leaves(b)):
+      xs = x.index_select(0, idx).to(torch.float64)
+      ys = xs if y is x else layout.like(y, x).index_select(0, idx).to(
+          torch.float64)
+      prod = xs * ys
+      if prod.dim() > 1:
+        prod = prod.reshape(prod.shape[0], -1).sum(dim=1)
+      t = torch.dot(prod, w)
+      tot = t if tot is None else tot + t
+    self.t[slot] -= tot
+
+  def dot_into(self, slot, a, b, dot_fn, reduce_fn, interface=None):
     """scalars[slot] = <a, b> summed over the leaves of the pytrees."""
     la, lb = _leaves(a), _leaves(b)
     if dot_fn is None:
@@ -75,6 +94,8 @@ class _Scalars:
       total = sum(dot_fn(x, y) for x, y in zip(la, lb))
       self.t[slot] = torch.as_tensor(total, dtype=torch.float64,
                                      device=self.t.device)
+    if interface is not None:
+      self.interface_correction(slot, a, b, interface)
     if reduce_fn is not None:
       reduce_fn(self.t[slot:slot + 1])
 
@@ -87,12 +108,16 @@ class CGRunner:
   """
 
   def __init__(self, A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None,
-               M=None, dot_fn=None, reduce_fn=None):
+               M=None, dot_fn=None, reduce_fn=None, interface=None):
+    if interface is not None and (M is not None or dot_fn is not None):
+      raise ValueError('interface weights apply to the plain dot of consistent '
+                       'vectors (M = None, dot_fn = None)')
     b_leaves = [_as_vec(l) for l in _leaves(b)]
     if not all(l.is_cuda for l in b_leaves):
       raise RuntimeError('swirl_fem_amd.linalg.cg runs on MI355X device '
                          'tensors (there is no CPU fallback)')
     self.A, self.M, self.dot_fn, self.reduce_fn = A, M, dot_fn, reduce_fn
+    self.interface = interface
     self.tol, self.atol = tol, atol
     if maxiter is None:
       maxiter = 10 * sum(l.numel() for l in b_leaves)
@@ -106,17 +131,17 @@ class CGRunner:
     self.s = s = _Scalars(device)
     S = _Scalars
     self.identity_m = M is None
-    s.dot_into(S.BB, b, b, dot_fn, reduce_fn)
+    s.dot_into(S.BB, b, b, dot_fn, reduce_fn, interface)
     self.r = _map(lambda bb, ax: bb - layout.like(ax, bb), b, A(self.x))
     z = self.r if self.identity_m else M(self.r)
     self.p = _map(lambda t, rr: layout.like(t, rr).clone(), z, self.r)
-    s.dot_into(S.GAMMA, self.r, z, dot_fn, reduce_fn)
+    s.dot_into(S.GAMMA, self.r, z, dot_fn, reduce_fn, interface)
     # operators exposing `apply_with_dot` hand back p.Ap with the apply
     self.fused_dot = (dot_fn is None and hasattr(A, 'apply_with_dot') and
                       isinstance(self.p, torch.Tensor))
     self.parts = s.partials if self.fused_dot else None
     _ops.cg_scalars(s.t, 2, maxiter, tol, atol, self.parts)
-    self.fuse_rr = self.identity_m and dot_fn is None and reduce_fn is None
+    self.fuse_rr = self.identity_m and dot_fn is None
     self.issued = 0
 
   def step(self):
@@ -138,6 +163,8 @@ class CGRunner:
       for xx, yy in zip(_leaves(self.p), _leaves(Ap)):
         _ops.dot(layout.flat(xx), layout.flat(layout.like(yy, xx)), s.t,
                  S.PAP, accumulate=True)
+      if self.interface is not None:
+        s.interface_correction(S.PAP, self.p, Ap, self.interface)
       if reduce_fn is not None:
         reduce_fn(s.t[S.PAP:S.PAP + 1])
     else:
@@ -149,6 +176,10 @@ class CGRunner:
                         layout.flat(layout.like(aa, xx)), s.t, self.fuse_rr)
     if self.fuse_rr:
       z = self.r
+      if self.interface is not None:
+        s.interface_correction(S.GAMMA_NEW, self.r, self.r, self.interface)
+      if reduce_fn is not None:
+        reduce_fn(s.t[S.GAMMA_NEW:S.GAMMA_NEW + 1])
     else:
       z = self.r if self.identity_m else M(self.r)
       if dot_fn is None:
@@ -176,7 +207,7 @@ class CGRunner:
 
 
 def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
-       dot_fn=None, reduce_fn=None, check_every=16):
+       dot_fn=None, reduce_fn=None, interface=None, check_every=16):
   """Solves A x = b with (preconditioned) conjugate gradients.
 
   Args:
@@ -191,6 +222,12 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
     reduce_fn: optional in-place reduction applied to every inner product
       (partitioned meshes pass an RCCL all-reduce; reference callers pass a
       psum-ing `dot_fn`).
+    interface: optional `(idx, w)` from `NeighborPlan.interface_weights`: all
+      vectors are consistent across partitions (A returns the *assembled*
+      result) and every plain dot is corrected on the interface nodes to count
+      each global node once.  Mathematically the same iterates as the
+      reference's partitioned convention (unassembled A, M = exchange,
+      navier_stokes.py:436-438) without the extra vector z = M r.
     check_every: the host polls the device convergence flag this often.
   Returns:
     (x, info) with info = {'residual': gamma, 'num_iterations': k}.
@@ -198,7 +235,7 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
   if not _leaves(b):
     return b, {'residual': 0.0, 'num_iterations': 0}
   run = CGRunner(A, b, x0, tol=tol, atol=atol, maxiter=maxiter, M=M,
-                 dot_fn=dot_fn, reduce_fn=reduce_fn)
+                 dot_fn=dot_fn, reduce_fn=reduce_fn, interface=interface)
   while run.issued < run.maxiter:
     for _ in range(min(check_every, run.maxiter - run.issued)):
       run.step()
