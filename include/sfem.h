@@ -265,7 +265,11 @@ int sfem_helmholtz_local(const sfem_helmholtz_args* args, sfem_stream_t stream);
  *                      phases 1 and 2 clear `partials` when it is given
  * sfem_cg_update_xr:   x += alpha p; r -= alpha Ap;  (cg.py:80-81)
  *                      fuse_rr != 0 also accumulates gamma_new += r.r (M = I)
- * sfem_cg_update_p:    p = z + beta p                (cg.py:84-85)          */
+ * sfem_cg_update_p:    p = z + beta p                (cg.py:84-85)
+ * sfem_cg_update_r / sfem_cg_update_xp: the same two updates regrouped into
+ *                      8 instead of 9 vector passes (bitwise the same result):
+ *                      r -= alpha Ap (+ gamma_new += r.r), then, once beta is
+ *                      known,  x += alpha p;  p = z + beta p                   */
 #define SFEM_CG_NSCALARS 16
 int sfem_dot(const void* a, const void* b, int64_t count, double* result,
              int dtype, sfem_stream_t stream);
@@ -278,6 +282,10 @@ int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,
                       sfem_stream_t stream);
 int sfem_cg_update_p(void* p, const void* z, int64_t count, double* scalars,
                      int dtype, sfem_stream_t stream);
+int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
+                     int fuse_rr, int dtype, sfem_stream_t stream);
+int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
+                      double* scalars, int dtype, sfem_stream_t stream);
 /* y = a*x + b*y (plain fused vector update used outside the CG core)         */
 int sfem_axpby(double a, const void* x, double b, void* y, int64_t count,
                int dtype, sfem_stream_t stream);

@@ -74,6 +74,8 @@ SIGNATURES = {
     'sfem_cg_update_xr': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32,
                           c_i32, c_ptr],
     'sfem_cg_update_p': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+    'sfem_cg_update_r': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_ptr],
+    'sfem_cg_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_axpby': [c_dbl, c_ptr, c_dbl, c_ptr, c_i64, c_i32, c_ptr],
     'sfem_abi_version': [],
 }

@@ -442,6 +442,22 @@ def cg_update_p(p, z, scalars):
         _stream(dev)), 'sfem_cg_update_p')
 
 
+def cg_update_r(r, ap, scalars, fuse_rr):
+  dev = _dev(r, ap, scalars)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_r(
+        _ptr(r), _ptr(ap), r.numel(), _ptr(scalars), int(fuse_rr),
+        _dtype_code(r), _stream(dev)), 'sfem_cg_update_r')
+
+
+def cg_update_xp(x, p, z, scalars):
+  dev = _dev(x, p, z, scalars)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_xp(
+        _ptr(x), _ptr(p), _ptr(z), x.numel(), _ptr(scalars), _dtype_code(x),
+        _stream(dev)), 'sfem_cg_update_xp')
+
+
 def axpby(a, x, b, y):
   """In place: y = a * x + b * y."""
   dev = _dev(x, y)

@@ -311,6 +311,84 @@ cg_update_p_kernel(T* __restrict__ p, const T* __restrict__ z, int64_t count,
   }
 }
 
+// 8-pass split of the two updates (instead of 9): the x update rides with the
+// p update, where p is in registers anyway.
+//   update_r : r -= alpha Ap (+ gamma_new += r.r)        reads r, Ap; writes r
+//   update_xp: x += alpha p;  p = z + beta p             reads x, p, z; writes x, p
+template <typename T, bool FUSE_RR>
+__global__ void __launch_bounds__(512)
+cg_update_r_kernel(T* __restrict__ r, const T* __restrict__ ap, int64_t count,
+                   double* __restrict__ scalars) {
+  if (scalars[7] != 0.0) return;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const T alpha = (T)(scalars[0] / scalars[1]);
+  const int64_t nvec = count / VN;
+  V* rv = reinterpret_cast<V*>(r);
+  const V* apv = reinterpret_cast<const V*>(ap);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    V rr = rv[i];
+    const V aa = apv[i];
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* re = reinterpret_cast<T*>(&rr) + c;
+      *re -= alpha * vget<T>(aa, c);
+      if (FUSE_RR) acc += (double)*re * (double)*re;
+    }
+    rv[i] = rr;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
+    const T rn = r[i] - alpha * ap[i];
+    r[i] = rn;
+    if (FUSE_RR) acc += (double)rn * (double)rn;
+  }
+  if (FUSE_RR) {
+    const double total = block_sum(acc);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&scalars[2], total);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+cg_update_xp_kernel(T* __restrict__ x, T* __restrict__ p,
+                    const T* __restrict__ z, int64_t count,
+                    const double* __restrict__ scalars) {
+  if (scalars[7] != 0.0) return;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const T alpha = (T)(scalars[0] / scalars[1]);
+  const T beta = (T)(scalars[2] / scalars[0]);
+  const int64_t nvec = count / VN;
+  V* xv = reinterpret_cast<V*>(x);
+  V* pv = reinterpret_cast<V*>(p);
+  const V* zv = reinterpret_cast<const V*>(z);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    V xx = xv[i], pp = pv[i];
+    const V zz = zv[i];
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* xe = reinterpret_cast<T*>(&xx) + c;
+      T* pe = reinterpret_cast<T*>(&pp) + c;
+      *xe += alpha * *pe;
+      *pe = vget<T>(zz, c) + beta * *pe;
+    }
+    xv[i] = xx;
+    pv[i] = pp;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
+    const T pi = p[i];
+    x[i] += alpha * pi;
+    p[i] = z[i] + beta * pi;
+  }
+}
+
 // One-thread bookkeeping between the vector kernels of an iteration.
 // phase 2 (init, after b.b -> [5] and gamma0 -> [0]):
 //     atol2 = max(tol^2 b.b, atol^2); clear pAp, iterations;
@@ -598,6 +676,38 @@ int sfem_cg_update_p(void* p, const void* z, int64_t count, double* scalars,
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
       cg_update_p_kernel<T>, dim3(stream_grid(count, 512 * 2)), dim3(512), 0,
       as_stream(stream), (T*)p, (const T*)z, count, scalars));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
+                     int fuse_rr, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_r: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(r && ap, "sfem_cg_update_r: null pointer");
+  DISPATCH_DTYPE(dtype, {
+    const int grid = stream_grid(count, 512 * 2);
+    if (fuse_rr)
+      hipLaunchKernelGGL((cg_update_r_kernel<T, true>), dim3(grid), dim3(512),
+                         0, as_stream(stream), (T*)r, (const T*)ap, count,
+                         scalars);
+    else
+      hipLaunchKernelGGL((cg_update_r_kernel<T, false>), dim3(grid), dim3(512),
+                         0, as_stream(stream), (T*)r, (const T*)ap, count,
+                         scalars);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
+                      double* scalars, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_xp: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(x && p && z, "sfem_cg_update_xp: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      cg_update_xp_kernel<T>, dim3(stream_grid(count, 512 * 2)), dim3(512), 0,
+      as_stream(stream), (T*)x, (T*)p, (const T*)z, count, scalars));
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

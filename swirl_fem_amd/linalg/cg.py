@@ -14,9 +14,10 @@ each iteration; once it fires every later kernel is a no-op, and the host only
 polls the flag every `check_every` iterations.  Iterates and iteration count
 are therefore identical to a loop that tests every iteration.
 
-Per iteration (M = identity): A(p); dot(p, Ap); x += a p, r -= a Ap fused with
-r.r; p = r + b p  ->  3 vector kernels, 11 N-vector passes instead
-of the reference's 13 un-fused ones.
+Per iteration (M = identity): A(p) with p.Ap fused into the operator's scatter
+stage when it offers `apply_with_dot`; r -= a Ap fused with r.r; then
+x += a p and p = r + b p in one kernel  ->  8 N-vector passes besides the
+apply (SURVEY 8d's fused model: 11; the reference's un-fused loop: 13).
 """
 
 from __future__ import annotations
@@ -170,10 +171,9 @@ class CGRunner:
     else:
       s.dot_into(S.PAP, self.p, Ap, dot_fn, reduce_fn)
     _ops.cg_scalars(s.t, 0, *args)
-    for xx, rr, pp, aa in zip(_leaves(self.x), _leaves(self.r),
-                              _leaves(self.p), _leaves(Ap)):
-      _ops.cg_update_xr(layout.flat(xx), layout.flat(rr), layout.flat(pp),
-                        layout.flat(layout.like(aa, xx)), s.t, self.fuse_rr)
+    for rr, aa in zip(_leaves(self.r), _leaves(Ap)):
+      _ops.cg_update_r(layout.flat(rr), layout.flat(layout.like(aa, rr)), s.t,
+                       self.fuse_rr)
     if self.fuse_rr:
       z = self.r
       if self.interface is not None:
@@ -191,8 +191,11 @@ class CGRunner:
       else:
         # after convergence the done flag guards every consumer of this slot
         s.dot_into(S.GAMMA_NEW, self.r, z, dot_fn, reduce_fn)
-    for pp, zz in zip(_leaves(self.p), _leaves(z)):
-      _ops.cg_update_p(layout.flat(pp), layout.flat(layout.like(zz, pp)), s.t)
+    # x += alpha p rides with the p update (p is in registers there): 8 vector
+    # passes per iteration instead of 9, same arithmetic
+    for xx, pp, zz in zip(_leaves(self.x), _leaves(self.p), _leaves(z)):
+      _ops.cg_update_xp(layout.flat(xx), layout.flat(pp),
+                        layout.flat(layout.like(zz, pp)), s.t)
     _ops.cg_scalars(s.t, 1, *args)
     self.issued += 1
 
