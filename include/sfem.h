@@ -244,6 +244,60 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* args, sfem_stream_t stream);
  * StokesVelocity.A_local / B_local (navier_stokes.py:220-236).               */
 int sfem_helmholtz_local(const sfem_helmholtz_args* args, sfem_stream_t stream);
 
+/* ------------------------------------------------- fused Stokes operators ---
+ * The P_N - P_{N-2} divergence D and pressure gradient D^T of
+ * navier_stokes/navier_stokes.py:313-338 as one kernel each (gather, 3 d
+ * sum-factorised derivative lines, cofactor geometry, projection onto /
+ * interpolation from the P - 2 Gauss pressure nodes, scatter):
+ *
+ *   sfem_stokes_div:     p_out = pressure.scatter(D_local(velocity.gather(s u)))
+ *       D_local(u)_k = sum_q phi_k(x_q) w_q detJ_q div u(x_q)          (:313-320)
+ *       `scale` (optional, same layout as u) multiplies u node by node as it is
+ *       gathered: E = D Q D^T applies Q = (dt/beta_k) B^-1 (:340-348) for free.
+ *   sfem_stokes_grad_t:  out = mask * velocity.scatter(Dt_local(pressure.gather(p)))
+ *       Dt_local(p)_{i,c} = sum_q w_q detJ_q p(x_q) d phi_i/d x_c      (:322-338)
+ *       DIRICHLET / SHARED bits of `enc` as in sfem_helmholtz_apply; the shared
+ *       range [zero_begin, zero_end) of `out` is cleared by the call.
+ *
+ * Both integrate on the velocity GLL points (the `quadrature` of :279-282).
+ * Geometry: SFEM_GEO_AFFINE / SFEM_GEO_MULTILINEAR evaluate the cofactors of
+ * the Jacobian from `geo_elem` (sfem_helmholtz_setup_multilinear) in registers;
+ * SFEM_GEO_POINT reads `kfac` (slots, ndim*ndim, Q) from sfem_stokes_setup:
+ *   kfac[e][a*ndim + c][q] = w_q detJ_q invjac[e][q][c][a].
+ * `interp` (HOST, (P, P-2) row-major) = pressure basis phi_k at the GLL points;
+ * `penc` (E, (P-2)^ndim) = pressure node ids (negative = skip) or NULL for
+ * e * (P-2)^ndim + k.  P = 3..12, ndim = 2, 3.                                */
+typedef struct sfem_stokes_args {
+  const void* u;          /* div: (N, ndim) velocity                           */
+  void* out;              /* grad_t: (N, ndim) result                          */
+  const void* p_in;       /* grad_t: (Np,) pressure                            */
+  void* p_out;            /* div: (Np,) result                                 */
+  const void* scale;      /* div: optional (N, ndim) per-node factor, or NULL  */
+  const int32_t* enc;     /* (E, n) encoded velocity indices                   */
+  const int32_t* penc;    /* (E, np) pressure node ids or NULL                 */
+  const void* kfac;       /* per-point weighted cofactors or NULL              */
+  const void* geo_elem;   /* (E, 24) or NULL                                   */
+  const int32_t* geo_index; /* (E,) slot of element e in kfac, or NULL = e     */
+  const int32_t* elem_list; /* element ids of this launch, or NULL = all       */
+  const void* dmat;       /* HOST (P, P)                                       */
+  const void* weights;    /* HOST (P,)                                         */
+  const void* nodes;      /* HOST (P,)                                         */
+  const void* interp;     /* HOST (P, P-2)                                     */
+  int64_t num_elements;
+  int64_t num_listed;
+  int64_t num_nodes;
+  int64_t zero_begin, zero_end;   /* grad_t only                               */
+  int32_t ndim, P, dtype, geo_mode;
+  int64_t node_stride, comp_stride;  /* layout of u / out / scale (0 = (N, ndim)
+                                        row-major)                             */
+} sfem_stokes_args;
+
+int sfem_stokes_setup(const void* invjac, const void* jacdet,
+                      const void* weights_nd, void* kfac, int64_t num_elements,
+                      int ndim, int Q, int dtype, sfem_stream_t stream);
+int sfem_stokes_div(const sfem_stokes_args* args, sfem_stream_t stream);
+int sfem_stokes_grad_t(const sfem_stokes_args* args, sfem_stream_t stream);
+
 /* ------------------------------------------------------------ CG kernels ---
  * Preconditioned CG of linalg/cg.py:30-97 with device-resident scalars: no
  * host synchronisation inside an iteration (the reference keeps its loop on

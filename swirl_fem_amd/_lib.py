@@ -36,6 +36,20 @@ class HelmholtzArgs(ctypes.Structure):
   ]
 
 
+class StokesArgs(ctypes.Structure):
+  """Mirror of `struct sfem_stokes_args`."""
+  _fields_ = [
+      ('u', c_ptr), ('out', c_ptr), ('p_in', c_ptr), ('p_out', c_ptr),
+      ('scale', c_ptr), ('enc', c_ptr), ('penc', c_ptr), ('kfac', c_ptr),
+      ('geo_elem', c_ptr), ('geo_index', c_ptr), ('elem_list', c_ptr),
+      ('dmat', c_ptr), ('weights', c_ptr), ('nodes', c_ptr), ('interp', c_ptr),
+      ('num_elements', c_i64), ('num_listed', c_i64), ('num_nodes', c_i64),
+      ('zero_begin', c_i64), ('zero_end', c_i64), ('ndim', c_i32),
+      ('P', c_i32), ('dtype', c_i32), ('geo_mode', c_i32),
+      ('node_stride', c_i64), ('comp_stride', c_i64),
+  ]
+
+
 GEO_POINT, GEO_AFFINE, GEO_MULTILINEAR = 0, 1, 3
 
 # name -> argument types (all functions return int unless noted)
@@ -77,6 +91,10 @@ SIGNATURES = {
     'sfem_cg_update_r': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_cg_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_axpby': [c_dbl, c_ptr, c_dbl, c_ptr, c_i64, c_i32, c_ptr],
+    'sfem_stokes_setup': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                          c_i32, c_ptr],
+    'sfem_stokes_div': [c_ptr, c_ptr],
+    'sfem_stokes_grad_t': [c_ptr, c_ptr],
     'sfem_abi_version': [],
 }
 

@@ -374,6 +374,79 @@ def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
   return out
 
 
+def stokes_setup(invjac, jacdet, weights_nd):
+  """Weighted cofactor planes (E, d*d, Q) for curved elements."""
+  invjac, jacdet = invjac.contiguous(), jacdet.contiguous()
+  dev = _dev(invjac, jacdet, weights_nd)
+  E, Q, d, _ = invjac.shape
+  kfac = torch.empty((E, d * d, Q), dtype=invjac.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_stokes_setup(
+        _ptr(invjac), _ptr(jacdet), _ptr(weights_nd), _ptr(kfac), E, d, Q,
+        _dtype_code(invjac), _stream(dev)), 'sfem_stokes_setup')
+  return kfac
+
+
+def _stokes_args(vec, enc, penc, part, host, ndim, P, zero_range, **ptrs):
+  node_stride = comp_stride = 0
+  if not vec.is_contiguous():
+    node_stride, comp_stride = 1, vec.stride(-1)
+  lst = part.get('elem_list')
+  return _lib.StokesArgs(
+      enc=_dptr(enc), penc=_dptr(penc), kfac=_dptr(part.get('kfac')),
+      geo_elem=_dptr(part.get('geo_elem')),
+      geo_index=_dptr(part.get('geo_index')), elem_list=_dptr(lst),
+      dmat=_hptr(host['dmat']), weights=_hptr(host['weights']),
+      nodes=_hptr(host['nodes']), interp=_hptr(host['interp']),
+      num_elements=enc.shape[0], num_listed=0 if lst is None else lst.numel(),
+      num_nodes=vec.shape[0], zero_begin=int(zero_range[0]),
+      zero_end=int(zero_range[1]), ndim=ndim, P=P, dtype=_dtype_code(vec),
+      geo_mode=part['geo_mode'], node_stride=node_stride,
+      comp_stride=comp_stride, **ptrs)
+
+
+def _check_field(u, ndim):
+  if u.dim() != 2 or u.shape[1] != ndim or not (
+      u.is_contiguous() or is_component_major(u)):
+    raise ValueError(f'expected a dense (N, {ndim}) velocity field')
+
+
+def stokes_div(u, p_out, enc, penc, parts, host, ndim, P, scale=None):
+  """p_out <- D(scale * u) (navier_stokes.py:313-333), one launch per
+  geometry kind."""
+  dev = _dev(enc, p_out)
+  _check_field(u, ndim)
+  if scale is not None:
+    _check_field(scale, ndim)
+    if scale.stride() != u.stride() or scale.dtype != u.dtype:
+      raise ValueError('scale must share layout and dtype with u')
+  host = {k: _host(v, u.dtype) for k, v in host.items()}
+  with torch.cuda.device(dev):
+    for part in parts:
+      args = _stokes_args(u, enc, penc, part, host, ndim, P, (0, 0),
+                          u=u.data_ptr(), p_out=p_out.data_ptr(),
+                          scale=_dptr(scale))
+      _lib.check(_lib.load().sfem_stokes_div(ctypes.byref(args), _stream(dev)),
+                 'sfem_stokes_div')
+  return p_out
+
+
+def stokes_grad_t(p, out, enc, penc, parts, host, ndim, P, zero_range):
+  """out <- mask * D^T p (navier_stokes.py:322-338)."""
+  dev = _dev(enc, p)
+  _check_field(out, ndim)
+  host = {k: _host(v, out.dtype) for k, v in host.items()}
+  with torch.cuda.device(dev):
+    for n, part in enumerate(parts):
+      args = _stokes_args(out, enc, penc, part, host, ndim, P,
+                          zero_range if n == 0 else (0, 0),
+                          out=out.data_ptr(), p_in=p.data_ptr())
+      _lib.check(_lib.load().sfem_stokes_grad_t(ctypes.byref(args),
+                                                _stream(dev)),
+                 'sfem_stokes_grad_t')
+  return out
+
+
 from swirl_fem_amd.core.layout import is_component_major  # noqa: E402
 
 

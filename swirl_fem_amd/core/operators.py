@@ -230,3 +230,150 @@ class FusedLinearOperator:
   def apply_with_dot(self, u, partials):
     """Returns A(u) and accumulates partial sums of u . A(u)."""
     return self.op.apply(u, self.lambda0, self.lambda1, dot_out=partials)
+
+
+# ---------------------------------------------------------------------------
+# Fused Stokes divergence / pressure gradient (P_N - P_{N-2})
+# ---------------------------------------------------------------------------
+def supports_fused_stokes(vspace, pspace) -> str | None:
+  """None if `sfem_stokes_div` / `sfem_stokes_grad_t` apply, else the reason."""
+  why = supports_fused(vspace)
+  if why is not None:
+    return why
+  P = vspace.mesh.gridpoints_1d.num_points
+  if P < 3:
+    return f'P={P} < 3'
+  if pspace.mesh.gridpoints_1d.num_points != P - 2:
+    return 'pressure space is not P - 2 points per direction'
+  if pspace.interpolator.evalpoints_1d != vspace.mesh.gridpoints_1d:
+    return 'pressure quadrature differs from the velocity nodes'
+  if pspace.mesh.num_elements != vspace.mesh.num_elements:
+    return 'velocity and pressure meshes have different elements'
+  # the kernels take w detJ at the quadrature points from the velocity
+  # geometry; the reference takes it from the pressure space (:313-320).  The
+  # two agree whenever both meshes refine one premesh.
+  jv, jp = vspace.jacdets, pspace.jacdets
+  tol = 1e-10 if jv.dtype == torch.float64 else 1e-4
+  if jv.shape != jp.shape or not bool(
+      ((jv - jp).abs() <= tol * jv.abs().amax()).all()):
+    return 'velocity and pressure spaces carry different geometry'
+  return None
+
+
+@dataclasses.dataclass(eq=False)
+class StokesDivGrad:
+  """`D` and `D^T` of navier_stokes/navier_stokes.py:313-338 as one kernel
+  each (`sfem_stokes_div`, `sfem_stokes_grad_t`)."""
+  vspace: object
+  pspace: object
+  parts: list
+  enc: torch.Tensor               # (E, n) encoded velocity indices
+  penc: torch.Tensor | None       # (E, np) pressure node ids; None = identity
+  host: dict
+  zero_range: tuple
+  num_pressure_nodes: int
+
+  @classmethod
+  def create(cls, vspace, pspace, dirichlet_mask=None,
+             geometry='auto') -> 'StokesDivGrad':
+    why = supports_fused_stokes(vspace, pspace)
+    if why is not None:
+      raise NotImplementedError(f'fused Stokes kernels unavailable: {why}')
+    if geometry not in ('auto', 'multilinear', 'stored'):
+      raise ValueError(f'unknown geometry mode {geometry!r}')
+    mesh = vspace.mesh
+    E = mesh.num_elements
+    w = torch.as_tensor(vspace.quadrature.weights_nd(mesh.ndim),
+                        dtype=vspace.dtype, device=vspace.device)
+    if geometry == 'stored':
+      kind = torch.zeros(E, dtype=torch.int32, device=vspace.device)
+      coef = None
+    else:
+      kind, coef = classify_geometry(vspace)
+      if geometry == 'multilinear':
+        kind = torch.where(kind == _GEO_AFFINE,
+                           torch.full_like(kind, _GEO_MULTILINEAR), kind)
+    parts = []
+    for k in (_GEO_AFFINE, _GEO_MULTILINEAR, _GEO_POINT):
+      sel = kind == k
+      count = int(sel.sum())
+      if count == 0:
+        continue
+      part = {'geo_mode': k}
+      if count < E:
+        part['elem_list'] = torch.nonzero(sel).reshape(-1).to(
+            torch.int32).contiguous()
+      if k == _GEO_POINT:
+        if count < E:
+          part['kfac'] = _ops.stokes_setup(vspace.invjacs[sel].contiguous(),
+                                           vspace.jacdets[sel].contiguous(), w)
+          part['geo_index'] = (torch.cumsum(sel, 0) - 1).to(
+              torch.int32).contiguous()
+        else:
+          part['kfac'] = _ops.stokes_setup(vspace.invjacs, vspace.jacdets, w)
+      else:
+        part['geo_elem'] = coef
+      parts.append(part)
+    plan = mesh.assembly_plan()
+    mask = None
+    if dirichlet_mask is not None:
+      mask = torch.as_tensor(dirichlet_mask, device=vspace.device)
+      mask = (mask != 0).to(torch.uint8).contiguous()
+    enc = _ops.encode_elements(mesh.elements, mask, plan.multiplicity)
+    pel = pspace.mesh.elements
+    ident = torch.arange(pel.numel(), device=pel.device,
+                         dtype=pel.dtype).reshape(pel.shape)
+    penc = None if torch.equal(pel, ident) else pel.to(torch.int32).contiguous()
+    host = {'dmat': vspace.interpolator._differentiation_matrix_1d(),
+            'weights': np.asarray(vspace.quadrature.weights),
+            'nodes': np.asarray(mesh.gridpoints_1d.node_values),
+            'interp': pspace.interpolator._interpolation_matrix_1d()}
+    return cls(vspace=vspace, pspace=pspace, parts=parts, enc=enc, penc=penc,
+               host=host, zero_range=plan.zero_range,
+               num_pressure_nodes=pspace.mesh.num_nodes)
+
+  def div(self, u, scale=None, out=None):
+    """(N, d) -> (Np,):  D (scale * u)."""
+    mesh = self.vspace.mesh
+    if tuple(u.shape) != (mesh.num_nodes, mesh.ndim):
+      raise ValueError(f'expected ({mesh.num_nodes}, {mesh.ndim}) velocity, '
+                       f'got {tuple(u.shape)}')
+    u = u.to(self.vspace.dtype)
+    if not (u.is_contiguous() or _ops.is_component_major(u)):
+      u = u.contiguous()
+    if scale is not None:
+      scale = _like_layout(scale.to(u.dtype).expand_as(u), u)
+    if out is None:
+      # pressure nodes that no element references (none on refiner meshes)
+      out = (torch.empty if self.penc is None else torch.zeros)(
+          self.num_pressure_nodes, dtype=u.dtype, device=u.device)
+    return _ops.stokes_div(u, out, self.enc, self.penc, self.parts, self.host,
+                           mesh.ndim, mesh.gridpoints_1d.num_points, scale)
+
+  def grad_t(self, p, out=None, component_major=False):
+    """(Np,) -> (N, d):  mask * D^T p."""
+    mesh = self.vspace.mesh
+    if tuple(p.shape) != (self.num_pressure_nodes,):
+      raise ValueError(f'expected ({self.num_pressure_nodes},) pressure, got '
+                       f'{tuple(p.shape)}')
+    p = p.to(self.vspace.dtype).contiguous()
+    if out is None:
+      shape = (mesh.num_nodes, mesh.ndim)
+      if component_major:
+        from swirl_fem_amd.core import layout
+        out = layout.empty_component_major(shape, p.dtype, p.device)
+      else:
+        out = torch.empty(shape, dtype=p.dtype, device=p.device)
+    return _ops.stokes_grad_t(p, out, self.enc, self.penc, self.parts,
+                              self.host, mesh.ndim,
+                              mesh.gridpoints_1d.num_points, self.zero_range)
+
+
+def _like_layout(t, ref):
+  """`t` (same shape as `ref`) materialised in the memory layout of `ref`."""
+  if t.stride() == ref.stride() and (t.is_contiguous() or
+                                     _ops.is_component_major(t)):
+    return t
+  out = torch.empty_like(ref)        # preserves the dense layout of ref
+  out.copy_(t)
+  return out

@@ -343,12 +343,31 @@ class StokesSEM:
     p = self.pressure.pspace.scalar_function(p_local)
     return self.velocity.vspace.local_covector(b, (v, p))
 
+  def _divgrad(self):
+    """Fused D / D^T kernels (`operators.StokesDivGrad`), or None when the
+    spaces are not eligible (then the generic q-function path runs)."""
+    if 'divgrad' not in self._cache:
+      op = None
+      if operators.supports_fused_stokes(self.velocity.vspace,
+                                         self.pressure.pspace) is None:
+        dirichlet = (self.velocity.interior_mask[:, 0] == 0)
+        op = operators.StokesDivGrad.create(self.velocity.vspace,
+                                            self.pressure.pspace, dirichlet)
+      self._cache['divgrad'] = op
+    return self._cache['divgrad']
+
   def D(self, u):
     """Velocity divergence matrix."""
+    op = self._divgrad()
+    if op is not None:
+      return op.div(u)
     return self.pressure.scatter(self.D_local(self.velocity.gather(u)))
 
   def Dt(self, p):
     """Apply the pressure gradient operator."""
+    op = self._divgrad()
+    if op is not None:
+      return op.grad_t(p)
     return self.velocity.interior_mask * self.velocity.scatter(
         self.Dt_local(self.pressure.gather(p)))
 
@@ -359,6 +378,20 @@ class StokesSEM:
 
   def E(self, p, dt: float, time_order: int):
     """Apply the operator E = D Q D^T."""
+    op = self._divgrad()
+    if op is not None:
+      # two kernels: D^T, then D with Q = (dt / beta_k) diag(QQ^T B)^-1 folded
+      # into its gather (plus the exchange on periodic / partitioned meshes)
+      key = ('q_scale', float(dt), int(time_order))
+      if key not in self._cache:
+        if 'diag_qqti' not in self._cache:
+          self._cache['diag_qqti'] = 1 / self.velocity.exchange(
+              self.velocity_mass_diag)
+        beta_k = float(bdfk_coeffs(time_order)[-1])
+        self._cache[key] = ((dt / beta_k) *
+                            self._cache['diag_qqti']).contiguous()
+      w = self.velocity.exchange(op.grad_t(p))
+      return op.div(w, scale=self._cache[key])
     return self.D(self.Q(self.Dt(p), dt=dt, time_order=time_order))
 
   # ------------------------------------------------------------- time stepping
