@@ -266,7 +266,7 @@ int sfem_helmholtz_local(const sfem_helmholtz_args* args, sfem_stream_t stream);
  *   kfac[e][a*ndim + c][q] = w_q detJ_q invjac[e][q][c][a].
  * `interp` (HOST, (P, P-2) row-major) = pressure basis phi_k at the GLL points;
  * `penc` (E, (P-2)^ndim) = pressure node ids (negative = skip) or NULL for
- * e * (P-2)^ndim + k.  P = 3..12, ndim = 2, 3.                                */
+ * e * (P-2)^ndim + k.  P = 4..12, ndim = 2, 3.                                */
 typedef struct sfem_stokes_args {
   const void* u;          /* div: (N, ndim) velocity                           */
   void* out;              /* grad_t: (N, ndim) result                          */

@@ -241,8 +241,8 @@ def supports_fused_stokes(vspace, pspace) -> str | None:
   if why is not None:
     return why
   P = vspace.mesh.gridpoints_1d.num_points
-  if P < 3:
-    return f'P={P} < 3'
+  if P < 4:
+    return f'P={P} < 4'
   if pspace.mesh.gridpoints_1d.num_points != P - 2:
     return 'pressure space is not P - 2 points per direction'
   if pspace.interpolator.evalpoints_1d != vspace.mesh.gridpoints_1d:

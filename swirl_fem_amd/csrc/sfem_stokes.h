@@ -536,12 +536,12 @@ int dispatch_stokes(const StokesParams<T>& prm, int P, bool grad_t,
     using T = TYPE;                                                          \
     constexpr int DIM = DIMV;                                                \
     switch (P) {                                                             \
-      SFEM_STOKES_CASE(3) SFEM_STOKES_CASE(4) SFEM_STOKES_CASE(5)            \
+      SFEM_STOKES_CASE(4) SFEM_STOKES_CASE(5)                                \
       SFEM_STOKES_CASE(6) SFEM_STOKES_CASE(7) SFEM_STOKES_CASE(8)            \
       SFEM_STOKES_CASE(9) SFEM_STOKES_CASE(10) SFEM_STOKES_CASE(11)          \
       SFEM_STOKES_CASE(12)                                                   \
       default:                                                               \
-        set_error("stokes: P=%d outside the compiled range 3..12", P);       \
+        set_error("stokes: P=%d outside the compiled range 4..12", P);       \
         return SFEM_EUNSUPPORTED;                                            \
     }                                                                        \
   }

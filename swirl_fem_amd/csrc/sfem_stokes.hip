@@ -49,8 +49,9 @@ static int check_stokes(const char* who, const sfem_stokes_args* a) {
   SFEM_REQUIRE(a, "%s: null args", who);
   SFEM_REQUIRE(a->num_elements >= 0 && (a->ndim == 2 || a->ndim == 3),
                "%s: bad sizes", who);
-  SFEM_REQUIRE(a->P >= 3 && a->P <= SFEM_MAX_P,
-               "%s: P=%d outside 3..%d", who, a->P, SFEM_MAX_P);
+  // (one Gauss node per direction cannot carry the pressure-space geometry)
+  SFEM_REQUIRE(a->P >= 4 && a->P <= SFEM_MAX_P,
+               "%s: P=%d outside 4..%d", who, a->P, SFEM_MAX_P);
   SFEM_REQUIRE(a->dtype == SFEM_F32 || a->dtype == SFEM_F64,
                "%s: unknown dtype %d", who, a->dtype);
   if (a->num_elements == 0) return SFEM_OK;

@@ -50,7 +50,7 @@ def build(ndim, n, P, dtype, jitter=0.15, scramble=True, shear=False, seed=3):
   return rng, vsp, psp, ov, op
 
 
-CASES = [(2, 3, 3), (2, 4, 6), (2, 2, 12), (3, 2, 4), (3, 2, 5), (3, 2, 8),
+CASES = [(2, 3, 4), (2, 4, 6), (2, 2, 12), (3, 2, 4), (3, 2, 5), (3, 2, 8),
          (3, 1, 12)]
 
 
