@@ -269,6 +269,51 @@ def _add_pairs(p, q):
   return tuple(out)
 
 
+def _pointwise_einsum(spec, *vals):
+  """`torch.einsum` for batched *tiny* contractions (value dims <= 4, batch =
+  elements x quadrature points).  torch lowers those to batched GEMMs with
+  3x3 matrices, which run far below HBM speed; here the operands are broadcast
+  over the joint index space and reduced elementwise instead."""
+  ins, out = spec.split('->')
+  ins = ins.split(',')
+  letters = []
+  for s_ in ins:
+    for c in s_[3:]:
+      if c not in letters:
+        letters.append(c)
+  sizes = {}
+  for s_, v in zip(ins, vals):
+    for c, n in zip(s_[3:], v.shape[v.dim() - len(s_[3:]):]):
+      sizes[c] = n
+  small = all(n <= 4 for n in sizes.values())
+  joint = 1
+  for n in sizes.values():
+    joint *= n
+  same_batch = all(
+      v.shape[:v.dim() - len(s_[3:])] == vals[0].shape[:vals[0].dim() -
+                                                       len(ins[0][3:])]
+      for s_, v in zip(ins, vals))
+  if (len(vals) < 2 or not small or joint > 64 or not same_batch or
+      any(len(set(s_[3:])) != len(s_[3:]) for s_ in ins)):
+    return torch.einsum(spec, *vals)
+  nb = vals[0].dim() - len(ins[0][3:])
+  prod = None
+  for s_, v in zip(ins, vals):
+    own = s_[3:]
+    order = [own.index(c) for c in letters if c in own]
+    v = v.permute(*range(nb), *[nb + k for k in order])
+    shape = list(v.shape[:nb]) + [sizes[c] if c in own else 1 for c in letters]
+    v = v.reshape(shape)
+    prod = v if prod is None else prod * v
+  keep = out[3:]
+  red = [nb + k for k, c in enumerate(letters) if c not in keep]
+  if red:
+    prod = prod.sum(dim=red)
+  left = [c for c in letters if c in keep]
+  prod = prod.expand(*prod.shape[:nb], *[sizes[c] for c in left])
+  return prod.permute(*range(nb), *[nb + left.index(c) for c in keep])
+
+
 # ----------------------------------------------------------------- functions
 def einsum(spec, *operands):
   """Pointwise einsum over value dims; at most one linear operand."""
@@ -278,7 +323,7 @@ def einsum(spec, *operands):
     raise ValueError('form is not linear in the placeholder function')
   vals = [o.val if _is_q(o) else o for o in operands]
   if not lin:
-    return QExpr(torch.einsum(','.join(ins) + '->' + out, *vals))
+    return QExpr(_pointwise_einsum(','.join(ins) + '->' + out, *vals))
   p = lin[0]
   op = operands[p]
   others_spec = [s for i, s in enumerate(ins) if i != p]
@@ -300,7 +345,7 @@ def einsum(spec, *operands):
   pb = op.pullback
 
   def pullback(ct):
-    return pb(torch.einsum(t_spec, ct, *others))
+    return pb(_pointwise_einsum(t_spec, ct, *others))
 
   return QExpr(shape=out_shape, pullback=pullback)
 

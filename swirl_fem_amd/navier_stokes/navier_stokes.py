@@ -73,9 +73,15 @@ def bdfk_coeffs(k: int) -> np.ndarray:
 def _pressure_project_out_nullspace(sem, p):
   """Remove the nullspace (all 1s vector) from p."""
   w = sem.pressure.exchange(p)
-  q = torch.ones_like(p)
-  return w - (torch.vdot(q, sem.pressure.B(w)) /
-              torch.vdot(q, sem.pressure.B(q))) * q
+  # The reference applies the pressure mass matrix twice per call,
+  # 1.B(w) / 1.B(1) (:73-78).  B is symmetric, so 1.B(w) = (B 1).w: the
+  # vector B 1 is built once and every later call is a dot product.
+  key = ('pressure_mass_ones', p.dtype)
+  if key not in sem._cache:
+    b1 = sem.pressure.B(torch.ones_like(p))
+    sem._cache[key] = (b1, torch.sum(b1))
+  b1, total = sem._cache[key]
+  return w - torch.vdot(b1, w) / total
 
 
 @enum.unique
