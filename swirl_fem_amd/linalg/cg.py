@@ -144,9 +144,17 @@ class CGRunner:
     _ops.cg_scalars(s.t, 2, maxiter, tol, atol, self.parts)
     self.fuse_rr = self.identity_m and dot_fn is None
     self.issued = 0
+    self._graph = None
 
   def step(self):
     """One iteration of cg.py:75-86, all on the device."""
+    if self._graph is not None:
+      self._graph.replay()
+      self.issued += 1
+      return
+    self._step_eager()
+
+  def _step_eager(self):
     s, S = self.s, _Scalars
     A, M, dot_fn, reduce_fn = self.A, self.M, self.dot_fn, self.reduce_fn
     args = (self.maxiter, self.tol, self.atol, self.parts)
@@ -199,6 +207,36 @@ class CGRunner:
     _ops.cg_scalars(s.t, 1, *args)
     self.issued += 1
 
+  def capture(self) -> bool:
+    """Records one iteration into a HIP graph; later `step()` calls replay it.
+
+    A CG iteration on a small mesh is a few dozen short launches (kernels,
+    memsets, scalar updates) and is bound by launch overhead, not by the GPU;
+    one graph launch per iteration removes that.  Everything an iteration
+    touches lives at fixed addresses (x, r, p, the scalars; temporaries come
+    from the graph's private pool) and no kernel needs the host, so the replay
+    is exact.  Returns False (and stays eager) if the operator or the
+    preconditioner does something that cannot be captured.
+    """
+    if self._graph is not None:
+      return True
+    if self.reduce_fn is not None:
+      return False                 # collectives stay on the eager path
+    self.step()                    # warm caches / lazy setup eagerly
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    issued = self.issued
+    try:
+      with torch.cuda.graph(graph):
+        self._step_eager()
+    except Exception:              # pylint: disable=broad-except
+      torch.cuda.synchronize()
+      self.issued = issued
+      return False
+    self.issued = issued           # capture records, it does not execute
+    self._graph = graph
+    return True
+
   def done(self) -> bool:
     """Synchronising poll of the device convergence flag."""
     return bool(self.s.t[_Scalars.DONE].item() != 0.0)
@@ -210,7 +248,8 @@ class CGRunner:
 
 
 def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
-       dot_fn=None, reduce_fn=None, interface=None, check_every=16):
+       dot_fn=None, reduce_fn=None, interface=None, check_every=16,
+       graph=False):
   """Solves A x = b with (preconditioned) conjugate gradients.
 
   Args:
@@ -231,6 +270,9 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
       each global node once.  Mathematically the same iterates as the
       reference's partitioned convention (unassembled A, M = exchange,
       navier_stokes.py:436-438) without the extra vector z = M r.
+    graph: replay the iteration as one HIP graph launch (`CGRunner.capture`);
+      worth it when an iteration is launch-bound (small meshes, long solves).
+      `A` and `M` must then be pure device work on fixed operands.
     check_every: the host polls the device convergence flag this often.
   Returns:
     (x, info) with info = {'residual': gamma, 'num_iterations': k}.
@@ -239,6 +281,8 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
     return b, {'residual': 0.0, 'num_iterations': 0}
   run = CGRunner(A, b, x0, tol=tol, atol=atol, maxiter=maxiter, M=M,
                  dot_fn=dot_fn, reduce_fn=reduce_fn, interface=interface)
+  if graph and dot_fn is None and run.maxiter > 2 and not run.done():
+    run.capture()
   while run.issued < run.maxiter:
     for _ in range(min(check_every, run.maxiter - run.issued)):
       run.step()

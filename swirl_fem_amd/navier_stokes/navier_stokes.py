@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import dataclasses
 import enum
+import os
 from collections.abc import Sequence
 from functools import partial
 from typing import Any
@@ -426,7 +427,12 @@ class StokesSEM:
     # component-major storage for the Helmholtz solve: every kernel of the CG
     # then works on contiguous component strips (same (N, d) shape for callers)
     f = layout.component_major(f)
-    u_star, info = cg(H_, f, M=self.velocity.exchange, tol=tol, atol=atol)
+    # single-partition solves replay each CG iteration as one HIP graph launch
+    # (iterations on small meshes are launch-bound); SFEM_GRAPHS=0 disables it
+    graph = (self.velocity.mesh.axis_name is None and
+             os.environ.get('SFEM_GRAPHS', '1') != '0')
+    u_star, info = cg(H_, f, M=self.velocity.exchange, tol=tol, atol=atol,
+                      graph=graph)
     if u_boundary is not None:
       u_star = u_star + u_boundary
     aux = {'u_star_info': info}
@@ -435,7 +441,7 @@ class StokesSEM:
 
     dp, info = cg(partial(self.E, dt=dt, time_order=time_order),
                   -self.D(u_star), M=pressure_preconditioner, tol=tol,
-                  atol=atol)
+                  atol=atol, graph=graph)
     aux['dp_info'] = info
 
     u = u_star + self.Q(self.Dt(dp), dt=dt, time_order=time_order)

@@ -636,6 +636,33 @@ def test_cg_with_fused_operator_dot():
 
 
 # ------------------------------------------------------------------ Poisson
+def test_cg_graph_replay_matches_eager():
+  """One HIP graph launch per iteration == the eager launch sequence."""
+  from swirl_fem_amd.linalg.cg import cg, CGRunner
+  rp = make_case(3, 3, 5, jitter=0.1, seed=4)
+  mesh, fes, _ = spaces(rp, 5, 5, 'gll')
+  bm = mesh.physical_masks['boundary']
+  op = fes.helmholtz_operator(bm)
+  rng = np.random.default_rng(8)
+  b = dev(rng.standard_normal(mesh.num_nodes)) * (~bm)
+  for A, M in ((op.linear_operator(0.5, 1.0), None),
+               (lambda u: op.apply(u, 0.5, 1.0), lambda r: 0.5 * r)):
+    x0, i0 = cg(A, b, tol=1e-12, maxiter=500, M=M)
+    x1, i1 = cg(A, b, tol=1e-12, maxiter=500, M=M, graph=True)
+    assert i0['num_iterations'] == i1['num_iterations'] > 10
+    assert float((x0 - x1).abs().max()) < 1e-12 * float(x0.abs().max())
+  run = CGRunner(op.linear_operator(0.5, 1.0), b, tol=1e-12, maxiter=500)
+  assert run.capture() and run._graph is not None
+  # an operator that synchronises cannot be captured: the solve stays eager
+  def syncing(u):
+    float(u[0])
+    return op.apply(u, 0.5, 1.0)
+  x3, i3 = cg(lambda u: op.apply(u, 0.5, 1.0), b, tol=1e-12, maxiter=500)
+  x2, i2 = cg(syncing, b, tol=1e-12, maxiter=500, graph=True)
+  assert i2['num_iterations'] == i3['num_iterations']
+  assert float((x3 - x2).abs().max()) < 1e-12 * float(x3.abs().max())
+
+
 def test_poisson_config1_matches_oracle_and_series():
   """BASELINE config 1: 2D Poisson, 16x16 quads on [-1,1]^2, p=3."""
   from swirl_fem_amd.examples.poisson import BCType, solve_poisson
