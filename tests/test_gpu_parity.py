@@ -399,6 +399,28 @@ def test_fused_helmholtz_fp64(ndim, n, P, geometry):
       _helmholtz_ref(ofes, u, 0., 1., None)).max())
 
 
+@pytest.mark.parametrize('name,ndim,P', [('cube.msh', 3, 4),
+                                         ('periodic_cube.msh', 3, 3),
+                                         ('kovasznay.msh', 2, 6)])
+def test_fused_helmholtz_on_gmsh_meshes(name, ndim, P):
+  """Reference data files (swirl_fem/testdata/*.msh) through the native Gmsh
+  reader, the refiner and the fused operator, against the oracle."""
+  from swirl_fem_amd.common import mesh_reader
+  pm = mesh_reader.read(os.path.join(os.path.dirname(__file__), 'golden',
+                                     'msh', name), ndim=ndim)
+  rp = refine_premesh(pm, Nodes1D.create(P, NT['gll']))
+  mesh, fes, ofes = spaces(rp, P, P, 'gll')
+  rng = np.random.default_rng(23)
+  x = rp.node_coords
+  lo, hi = x.min(axis=0), x.max(axis=0)
+  dirichlet = (np.isclose(x[:, 0], lo[0]) | np.isclose(x[:, 0], hi[0]))
+  u = rng.standard_normal(mesh.num_nodes)
+  op = fes.helmholtz_operator(dev(dirichlet))
+  ref = _helmholtz_ref(ofes, u, 0.3, 1.0, dirichlet)
+  assert relerr(op.apply(dev(u), 0.3, 1.0), ref) < 1e-10
+  assert op.num_affine + op.num_multilinear == mesh.num_elements
+
+
 @pytest.mark.parametrize('ndim,n,P', [(2, 3, 6), (3, 2, 4), (3, 2, 8),
                                       (3, 1, 12)])
 def test_fused_helmholtz_fp32_and_vector(ndim, n, P):
