@@ -137,6 +137,9 @@ def main():
                   help="N>1 CG formulation: consistent vectors with the "
                        "exchange inside A (default) or the reference's "
                        'unassembled A with M = exchange')
+  ap.add_argument('--no-overlap', action='store_true',
+                  help='N>1: do not overlap the interface exchange with the '
+                       'interior elements')
   ap.add_argument('--jitter', type=float, default=0.0,
                   help='smooth mesh deformation amplitude (fraction of h)')
   args = ap.parse_args()
@@ -201,6 +204,10 @@ def main():
     # consistent vectors: exchange inside A on the interface nodes only, fused
     # p.Ap, interface-corrected r.r (distributed/solver.py)
     from swirl_fem_amd.distributed import solver
+    if not args.no_overlap:
+      # partition-boundary elements first; the interface exchange then runs
+      # on RCCL's stream while the interior elements compute
+      A = solver.OverlappedHelmholtz(op, part.plan, args.mass_coeff, 1.0)
     run = solver.make_runner(A, b, part.plan, tol=0.0, atol=0.0,
                              maxiter=10 ** 9)
   elif world > 1:
@@ -310,7 +317,10 @@ def main():
                             args.n, args.p, args.dtype),
             'elements_per_gpu': E, 'dofs_global': N_global,
             'blocks': 'x'.join(map(str, block_grid(world))),
-            'partitioned_cg': args.partitioned if world > 1 else None,
+            'partitioned_cg': (args.partitioned + (
+                '' if args.no_overlap or args.partitioned != 'consistent'
+                else ', exchange overlapped with interior elements'))
+            if world > 1 else None,
             'backend': ('rccl' if args.backend == 'nccl' else 'gloo '
                         '(rehearsal)') if world > 1 else None,
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,

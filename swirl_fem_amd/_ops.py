@@ -363,6 +363,8 @@ def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
   dev = _dev(enc)
   _check_vector_layout(u, out)
   host = {k: _host(v, u.dtype) for k, v in host.items()}
+  if not parts and zero_range[1] > zero_range[0]:
+    out[zero_range[0]:zero_range[1]].zero_()
   with torch.cuda.device(dev):
     for n, part in enumerate(parts):
       args = _helmholtz_args(u, out, part.get('enc', enc), part, host, ndim,

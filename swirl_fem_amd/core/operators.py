@@ -182,6 +182,31 @@ class HelmholtzOperator:
                num_multilinear=counts[_GEO_MULTILINEAR],
                num_curved=counts[_GEO_POINT])
 
+  def split(self, element_mask):
+    """Two operators over the elements inside / outside `element_mask` (E,)
+    that together equal this one; they share all device data.  Used to apply
+    the partition-boundary elements first so that the interface exchange
+    overlaps with the interior elements (`distributed/solver.py`)."""
+    if any(p.get('colored') for p in self.parts):
+      raise NotImplementedError('split() of a coloured operator')
+    mask = torch.as_tensor(element_mask, device=self.enc.device).to(torch.bool)
+    E = self.enc.shape[0]
+    if mask.shape != (E,):
+      raise ValueError(f'expected an ({E},) element mask')
+    halves = []
+    for keep in (mask, ~mask):
+      parts = []
+      for part in self.parts:
+        if 'elem_list' in part:
+          lst = part['elem_list']
+          lst = lst[keep[lst.to(torch.int64)]]
+        else:
+          lst = torch.nonzero(keep).reshape(-1).to(torch.int32)
+        if lst.numel():
+          parts.append(dict(part, elem_list=lst.contiguous()))
+      halves.append(dataclasses.replace(self, parts=parts))
+    return tuple(halves)
+
   def apply(self, u, lambda0=0.0, lambda1=1.0, out=None, *, zero=True,
             dot_out=None):
     """u (N,) or (N, nc) -> mask * scatter((l0 B + l1 A)_local(gather(u))).

@@ -168,6 +168,40 @@ def neighbor_exchange_(u: torch.Tensor, plan: NeighborPlan,
   return _ops.unpack_add_atomic(recv, cat, u)
 
 
+def neighbor_exchange_start(u: torch.Tensor, plan: NeighborPlan, group=None):
+  """First half of `neighbor_exchange_`: packs the interface values of `u` and
+  posts the grouped send/recv without waiting.  RCCL runs the transfers on its
+  own stream, so kernels enqueued before `neighbor_exchange_finish` (the
+  interior elements of an operator) overlap with them.  `u` must not change at
+  the interface nodes in between."""
+  from swirl_fem_amd import _ops
+  if not plan.neighbors:
+    return None
+  cat, sizes = plan.concat_indices(u.device)
+  send = _ops.pack_strided(u, cat)
+  recv = torch.empty_like(send)
+  sends, recvs = list(torch.split(send, sizes)), list(torch.split(recv, sizes))
+  if send.is_cuda and dist.get_backend(group) == 'gloo':
+    exchange_buffers(plan, sends, group=group, recv_bufs=recvs)   # blocking
+    return (recv, cat, [], send)
+  ops = []
+  for q, sb, rb in zip(plan.neighbors, sends, recvs):
+    ops.append(dist.P2POp(dist.isend, sb, q, group=group))
+    ops.append(dist.P2POp(dist.irecv, rb, q, group=group))
+  return (recv, cat, dist.batch_isend_irecv(ops), send)
+
+
+def neighbor_exchange_finish(handle, u: torch.Tensor) -> torch.Tensor:
+  """Second half: waits for the transfers and adds the neighbours' values."""
+  from swirl_fem_amd import _ops
+  if handle is None:
+    return u
+  recv, cat, reqs, _send = handle
+  for req in reqs:
+    req.wait()
+  return _ops.unpack_add_atomic(recv, cat, u)
+
+
 def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
   """In-place sum over ranks (the CG scalars; one fused all-reduce)."""
   if dist.is_available() and dist.is_initialized() and get_world_size() > 1:

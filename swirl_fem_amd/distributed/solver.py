@@ -41,19 +41,63 @@ class PartitionedOperator:
     return comm.neighbor_exchange_(w, self.plan, self.group)
 
 
+class OverlappedHelmholtz:
+  """`u -> QQ^T (l0 B + l1 A)_local u` with the interface exchange hidden
+  behind the interior elements:
+
+      boundary elements  ->  pack + post send/recv  ->  interior elements
+                                       (RCCL stream)        (compute stream)
+                         ->  wait + unpack-add
+
+  An element is a boundary element when it holds an interface node; those
+  are ~9 % of a 64^3 block, so the exchange (about 1.2 M values per GPU at
+  p = 7) overlaps with ~90 % of the apply.  Also hands CG its fused p.Ap.
+  """
+
+  def __init__(self, op, plan: comm.NeighborPlan, lambda0=0.0, lambda1=1.0,
+               group=None):
+    mesh = op.fespace.mesh
+    idx, _ = plan.interface_weights(op.enc.device)
+    on_iface = torch.zeros(mesh.num_nodes + 1, dtype=torch.bool,
+                           device=op.enc.device)
+    on_iface[idx] = True
+    boundary = on_iface[mesh.elements.to(torch.int64)].any(dim=1)  # -1 -> pad
+    self.boundary_op, self.interior_op = op.split(boundary)
+    self.plan, self.group = plan, group
+    self.lambda0, self.lambda1 = lambda0, lambda1
+    self.num_boundary_elements = int(boundary.sum())
+
+  def _apply(self, u, partials):
+    l0, l1 = self.lambda0, self.lambda1
+    out = self.boundary_op.apply(u, l0, l1, dot_out=partials)
+    handle = comm.neighbor_exchange_start(out, self.plan, self.group)
+    self.interior_op.apply(u, l0, l1, out=out, zero=False, dot_out=partials)
+    return comm.neighbor_exchange_finish(handle, out)
+
+  def __call__(self, u):
+    return self._apply(u, None)
+
+  def apply_with_dot(self, u, partials):
+    return self._apply(u, partials)
+
+
 def make_runner(local_op, b_local, plan: comm.NeighborPlan, *, x0=None,
                 tol=1e-5, atol=0.0, maxiter=None, group=None,
                 assembled_rhs=False) -> cg_lib.CGRunner:
   """CGRunner for `QQ^T A_local x = QQ^T b_local` on this rank's partition.
 
   `b_local` is the unassembled local covector (as `local_covector` returns it)
-  unless `assembled_rhs`; `x0`, if given, must be consistent.
+  unless `assembled_rhs`; `x0`, if given, must be consistent.  `local_op` is a
+  rank-local operator (wrapped in `PartitionedOperator`) or an
+  `OverlappedHelmholtz`, which already returns the assembled result.
   """
   b = b_local if assembled_rhs else comm.neighbor_exchange_(
       b_local.clone(), plan, group)
   reduce_fn = lambda t: comm.all_reduce_sum_(t, group)
+  A = (local_op if isinstance(local_op, OverlappedHelmholtz)
+       else PartitionedOperator(local_op, plan, group))
   return cg_lib.CGRunner(
-      PartitionedOperator(local_op, plan, group), b, x0, tol=tol, atol=atol,
+      A, b, x0, tol=tol, atol=atol,
       maxiter=maxiter, reduce_fn=reduce_fn,
       interface=plan.interface_weights(b.device))
 

@@ -54,6 +54,11 @@ def _worker(rank, world, port, grid, n, P, dtype_name, results):
     b_local = A(x_true)                                  # unassembled
     tol = 1e-12 if dtype == torch.float64 else 1e-5
     xs, info = solver.cg(A, b_local, part.plan, tol=tol, maxiter=2000)
+    # boundary elements first, exchange overlapped with the interior elements
+    Ao = solver.OverlappedHelmholtz(op, part.plan, 0.3, 1.0)
+    assert 0 < Ao.num_boundary_elements <= mesh.num_elements
+    xo, info_o = solver.cg(Ao, b_local, part.plan, tol=tol, maxiter=2000)
+    w_ref = comm.neighbor_exchange_(A(x_true), part.plan)
     xr, info_r = cg(A, b_local, tol=tol, maxiter=2000, M=mesh.exchange,
                     reduce_fn=part.reduce_sum_)
     # in-place single-launch exchange == reference-style exchange
@@ -67,6 +72,9 @@ def _worker(rank, world, port, grid, n, P, dtype_name, results):
         err=float((xs - x_true).abs().max() / x_true.abs().max()),
         err_ref=float((xs - xr).abs().max() / x_true.abs().max()),
         its=info['num_iterations'], its_ref=info_r['num_iterations'],
+        its_o=info_o['num_iterations'],
+        err_o=float((xo - xs).abs().max() / x_true.abs().max()),
+        app_o=float((Ao(x_true) - w_ref).abs().max() / w_ref.abs().max()),
         res=float(info['residual']),
         ex12=float((e1 - e2).abs().max()), ex13=float((e1 - e3).abs().max()),
         shared=part.plan.num_shared)
@@ -93,6 +101,9 @@ def test_partitioned_cg_on_one_gpu(grid, n, P, dtype_name):
     assert res[r]['shared'] > 0
     assert res[r]['err'] < (1e-9 if f64 else 2e-4), res[r]
     assert res[r]['err_ref'] < (1e-9 if f64 else 2e-4), res[r]
+    assert res[r]['err_o'] < (1e-9 if f64 else 2e-4), res[r]
+    assert res[r]['app_o'] < (1e-12 if f64 else 1e-5), res[r]
+    assert abs(res[r]['its_o'] - res[r]['its']) <= 1, res[r]
     assert res[r]['ex12'] < (1e-13 if f64 else 1e-5), res[r]
     assert res[r]['ex13'] < (1e-13 if f64 else 1e-5), res[r]
     # replicated scalars: every rank stops at the same iteration
