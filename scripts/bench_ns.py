@@ -1,0 +1,34 @@
+"""Navier-Stokes step timing on one MI355X (BASELINE configs 3 and 4 shapes).
+
+Prints one JSON line per case: wall time per step (setup excluded, first step
+excluded as warm-up), CG iteration counts, DOFs.  Not the contract bench
+(`bench.py` is); evidence for the caller rows of SURVEY 8 (a14).
+  python scripts/bench_ns.py [cavity] [tgv16] [tgv32]
+"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from swirl_fem_amd.examples import navier_stokes_driver as drv
+
+CASES = {
+    'cavity': dict(fn='lid_driven_cavity', kw=dict(n=32, order=5, reynolds=100.0, dt=1e-3, steps=8, tol=1e-8),
+                   name='2D lid-driven cavity, 32x32 quads, p=5 (config 3 shape)'),
+    'tgv16': dict(fn='taylor_green', kw=dict(n=16, order=7, reynolds=1600.0, dt=1e-3, steps=4, tol=1e-6),
+                  name='3D Taylor-Green, 16^3 hexes, p=7, triply periodic'),
+    'tgv32': dict(fn='taylor_green', kw=dict(n=32, order=7, reynolds=1600.0, dt=1e-3, steps=4, tol=1e-6),
+                  name='3D Taylor-Green, 32^3 hexes, p=7, triply periodic (1/8 of a config-4 GPU block)'),
+}
+for key in (sys.argv[1:] or ['cavity', 'tgv16']):
+  c = CASES[key]; prof = {}
+  sem, u, p, diag = getattr(drv, c['fn'])(device='cuda:0', profile=prof, **c['kw'])
+  steps = prof['step_s'][1:]
+  nv = sem.velocity.mesh.num_nodes; d = sem.velocity.mesh.ndim
+  print(json.dumps({
+      'case': c['name'], 'ms_per_step': 1e3 * float(np.mean(steps)), 'steps_timed': len(steps),
+      'first_step_ms': 1e3 * prof['step_s'][0], 'setup_s': prof['setup_s'],
+      'velocity_dofs': nv * d, 'pressure_dofs': sem.pressure.pspace.mesh.num_nodes,
+      'cg_iterations_helmholtz_pressure': diag['cg_iterations'][1:],
+      'max_divergence': diag['max_divergence'], 'dtype': 'f64',
+      'hip_graphs': os.environ.get('SFEM_GRAPHS', '1') != '0',
+      'peak_memory_gb': torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+  del sem, u, p; torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()

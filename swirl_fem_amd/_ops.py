@@ -129,16 +129,16 @@ def scatter_csr(u_local, offsets, slots, num_nodes, ncomp=1):
 _unique_cache = {}
 
 
-def exchange_local(u, gather_indices, unique_indices):
-  """Unpartitioned QQ^T; `unique_indices` is a host array (static)."""
-  if is_component_major(u):
-    out = torch.empty_like(u)
-    for k in range(u.shape[-1]):
-      out[:, k].copy_(exchange_local(u[:, k], gather_indices, unique_indices))
-    return out
-  u = u.contiguous()
+def exchange_local(u, gather_indices, unique_indices, inplace=False):
+  """Unpartitioned QQ^T; `unique_indices` is a host array (static).
+
+  `inplace=True` overwrites `u` (only its periodic images change): no copy of
+  the field, which is most of the cost of this operation."""
   gidx = _idx(gather_indices)
-  dev = _dev(u, gidx)
+  cm = is_component_major(u)
+  if not cm:
+    u = u.contiguous()
+  dev = _dev(u.movedim(-1, 0) if cm else u, gidx)
   key = (id(unique_indices), str(dev))
   cached = _unique_cache.get(key)
   if cached is None or cached[0] is not unique_indices:
@@ -147,14 +147,25 @@ def exchange_local(u, gather_indices, unique_indices):
     num_unique = int(unique_indices.max()) + 1 if len(unique_indices) else 0
     _unique_cache[key] = cached = (unique_indices, uni, num_unique)
   _, uni, num_unique = cached
-  ncomp = 1 if u.dim() == 1 else u.shape[-1]
-  out = torch.empty_like(u)
-  sums = torch.empty((max(num_unique, 1), ncomp), dtype=u.dtype, device=dev)
+  lib = _lib.load()
+
+  def run(src, dst, ncomp):
+    sums = torch.empty((max(num_unique, 1), ncomp), dtype=u.dtype, device=dev)
+    _lib.check(lib.sfem_exchange_local(
+        _ptr(src), _ptr(dst), _ptr(gidx), _ptr(uni), gidx.numel(),
+        src.shape[0], _ptr(sums), num_unique, ncomp, _dtype_code(u),
+        _stream(dev)), 'sfem_exchange_local')
+
   with torch.cuda.device(dev):
-    _lib.check(_lib.load().sfem_exchange_local(
-        _ptr(u), _ptr(out), _ptr(gidx), _ptr(uni), gidx.numel(), u.shape[0],
-        _ptr(sums), num_unique, ncomp, _dtype_code(u), _stream(dev)),
-        'sfem_exchange_local')
+    if cm:
+      # every component is a contiguous strip: exchange each one in place
+      out = u if inplace else u.clone()       # clone keeps the dense layout
+      strips = out.movedim(-1, 0)
+      for k in range(strips.shape[0]):
+        run(strips[k], strips[k], 1)
+      return out
+    out = u if inplace else torch.empty_like(u)
+    run(u, out, 1 if u.dim() == 1 else u.shape[-1])
   return out
 
 

@@ -15,6 +15,8 @@ same operators:
 
 from __future__ import annotations
 
+import time
+
 import numpy as np
 import torch
 
@@ -47,6 +49,34 @@ def navier_stokes_step(sem: StokesSEM, us, ps, Cus, *, reynolds: float,
   return u, p, sem.C(u), aux
 
 
+class _StepTimer:
+  """Optional wall-clock record of a driver run: `profile['setup_s']` and one
+  entry of `profile['step_s']` per time step (device-synchronised)."""
+
+  def __init__(self, profile, device):
+    self.profile, self.device = profile, device
+    self.t0 = time.perf_counter()
+    if profile is not None:
+      profile['step_s'] = []
+
+  def _sync(self):
+    if torch.cuda.is_available():
+      torch.cuda.synchronize(self.device)
+
+  def setup_done(self):
+    if self.profile is not None:
+      self._sync()
+      self.profile['setup_s'] = time.perf_counter() - self.t0
+      self.t0 = time.perf_counter()
+
+  def step_done(self):
+    if self.profile is not None:
+      self._sync()
+      now = time.perf_counter()
+      self.profile['step_s'].append(now - self.t0)
+      self.t0 = now
+
+
 def _histories(sem, u0, p0, time_order):
   us = tuple(u0 for _ in range(time_order))
   ps = tuple(p0 for _ in range(time_order))
@@ -55,8 +85,10 @@ def _histories(sem, u0, p0, time_order):
 
 
 def lid_driven_cavity(n=8, order=5, reynolds=100.0, dt=1e-3, steps=10,
-                      time_order=3, device=None, premesh=None, tol=1e-8):
+                      time_order=3, device=None, premesh=None, tol=1e-8,
+                      profile=None):
   """2D lid-driven cavity on [0,1]^2; returns (sem, u, p, diagnostics)."""
+  timer = _StepTimer(profile, device)
   pm = premesh if premesh is not None else unit_cube_mesh(n, ndim=2)
   sem = StokesSEM.create(pm, {'boundary': (BCType.DIRICHLET, 0.0)},
                          order=order, device=device)
@@ -70,11 +102,13 @@ def lid_driven_cavity(n=8, order=5, reynolds=100.0, dt=1e-3, steps=10,
                    device=x.device)
   us, ps, Cus = _histories(sem, u0, p0, time_order)
   iters = []
+  timer.setup_done()
   for _ in range(steps):
     u, p, Cu, aux = navier_stokes_step(
         sem, us, ps, Cus, reynolds=reynolds, dt=dt, time_order=time_order,
         u_boundary=u_b, tol=tol, atol=0.0)
     us, ps, Cus = us[1:] + (u,), ps[1:] + (p,), Cus[1:] + (Cu,)
+    timer.step_done()
     iters.append((aux['u_star_info']['num_iterations'],
                   aux['dp_info']['num_iterations']))
   diag = {'cg_iterations': iters,
@@ -85,8 +119,9 @@ def lid_driven_cavity(n=8, order=5, reynolds=100.0, dt=1e-3, steps=10,
 
 
 def taylor_green(n=4, order=3, reynolds=100.0, dt=1e-2, steps=5, time_order=3,
-                 device=None, tol=1e-8):
+                 device=None, tol=1e-8, profile=None):
   """3D Taylor-Green vortex on the periodic box [0, 2 pi]^3."""
+  timer = _StepTimer(profile, device)
   pm = unit_cube_mesh(n, ndim=3, a=0.0, b=2 * np.pi, periodic_dims=(0, 1, 2))
   sem = StokesSEM.create(pm, {}, order=order, device=device)
   x = sem.velocity.mesh.node_coords
@@ -101,11 +136,13 @@ def taylor_green(n=4, order=3, reynolds=100.0, dt=1e-2, steps=5, time_order=3,
   w = sem.velocity_mass_diag
   energy = [float(0.5 * (w * u0 ** 2).sum())]
   iters = []
+  timer.setup_done()
   for _ in range(steps):
     u, p, Cu, aux = navier_stokes_step(
         sem, us, ps, Cus, reynolds=reynolds, dt=dt, time_order=time_order,
         tol=tol, atol=0.0)
     us, ps, Cus = us[1:] + (u,), ps[1:] + (p,), Cus[1:] + (Cu,)
+    timer.step_done()
     energy.append(float(0.5 * (w * u ** 2).sum()))
     iters.append((aux['u_star_info']['num_iterations'],
                   aux['dp_info']['num_iterations']))
