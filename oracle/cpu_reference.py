@@ -1,0 +1,72 @@
+"""Multi-threaded CPU restatement of the reference's CG iteration -- TEST /
+BENCH INFRASTRUCTURE ONLY (imported by tests/ and by bench.py's cpu_baseline
+leg; never by swirl_fem_amd/).
+
+Same algorithm as `oracle/sfem_oracle.py` (= the reference): dense Kronecker
+gradient matrix G (Q, n, d) applied to every element (core/interpolation.py:
+288-292), 9 + 1 stored geometric arrays (core/fespace.py:338-346), the
+transposed application (core/fespace.py:458-471), scatter-add, un-fused PCG
+(linalg/cg.py:75-86) -- but with the element-batch contractions handed to
+torch-CPU GEMMs so that all host cores work, which is how XLA-CPU would run
+the reference's einsums.  Checked against the NumPy oracle in
+tests/test_oracle_pins.py; parity is pinned there, not here.
+"""
+
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from oracle import sfem_oracle as O
+
+
+class StiffnessCG:
+  """Dirichlet Laplacian A = mask * scatter(A_loc(gather(.))) + plain CG."""
+
+  def __init__(self, node_coords, elements, P, dirichlet):
+    fes = O.FESpace(node_coords, elements, (P, 'gll'), (P, 'gll'))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    self.num_nodes = fes.num_nodes
+    self.elements = t(fes.elements.astype(np.int64))
+    Q, n, d = fes.G.shape
+    self.Q, self.n, self.d = Q, n, d
+    self.G2 = t(fes.G.transpose(0, 2, 1).reshape(Q * d, n))   # (Q d, n)
+    self.invjacs = t(fes.invjacs)                              # (E, Q, d, d)
+    self.wdet = t(fes.jacdets * fes.weights[None, :])          # (E, Q)
+    self.interior = t(1.0 - np.asarray(dirichlet, dtype=np.float64))
+
+  def apply(self, u):
+    E = self.elements.shape[0]
+    ul = u[self.elements]                                      # gather (E, n)
+    ref = (ul @ self.G2.T).reshape(E, self.Q, self.d)          # GEMM
+    grad = torch.einsum('mqi,mqji->mqj', ref, self.invjacs)
+    flux = torch.einsum('mqj,mqji->mqi', grad * self.wdet[..., None],
+                        self.invjacs)
+    loc = flux.reshape(E, self.Q * self.d) @ self.G2           # GEMM (E, n)
+    out = torch.zeros(self.num_nodes, dtype=u.dtype)
+    out.index_add_(0, self.elements.reshape(-1), loc.reshape(-1))
+    return self.interior * out
+
+  def cg_iterations(self, b, iters=None, budget_s=None):
+    """Un-fused CG body; returns (x, iterations, seconds)."""
+    x = torch.zeros_like(b)
+    r = b - self.apply(x)
+    p = r.clone()
+    gamma = torch.dot(r, r)
+    self.apply(p)                                  # warm-up
+    k, t0 = 0, time.perf_counter()
+    while True:
+      Ap = self.apply(p)
+      alpha = gamma / torch.dot(p, Ap)
+      x = x + alpha * p
+      r = r - alpha * Ap
+      g2 = torch.dot(r, r)
+      p = r + (g2 / gamma) * p
+      gamma = g2
+      k += 1
+      el = time.perf_counter() - t0
+      if (iters is not None and k >= iters) or (
+          budget_s is not None and k >= 3 and el > budget_s):
+        return x, k, el
