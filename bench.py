@@ -73,17 +73,25 @@ def cpu_baseline(P, budget_s=12.0):
                       Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE))
   mask = np.zeros(rp.num_nodes)
   mask[np.unique(rp.physical_groups['boundary'])] = 1.0
-  ref = cpu_reference.StiffnessCG(rp.node_coords, rp.elements, P, mask)
-  rng = np.random.default_rng(0)
-  b = torch.from_numpy((1.0 - mask) * rng.standard_normal(rp.num_nodes))
-  _, iters, el = ref.cg_iterations(b, budget_s=budget_s)
+  # the GPU box shares its host: a rank gets about 16 cores, and the small
+  # GEMMs of this sample slow down when spread over every hardware thread
+  saved = torch.get_num_threads()
+  torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+  try:
+    ref = cpu_reference.StiffnessCG(rp.node_coords, rp.elements, P, mask)
+    rng = np.random.default_rng(0)
+    b = torch.from_numpy((1.0 - mask) * rng.standard_normal(rp.num_nodes))
+    _, iters, el = ref.cg_iterations(b, budget_s=budget_s)
+    threads = torch.get_num_threads()
+  finally:
+    torch.set_num_threads(saved)
   return {
       'value': rp.num_nodes * iters / el / 1e9, 'unit': 'GDOF/s',
-      'cores': torch.get_num_threads(), 'kind': 'port',
+      'cores': threads, 'kind': 'port',
       'sample': f'{ne}^3 hex elements p={P - 1} ({rp.num_nodes} DOFs), {iters} '
                 f'CG iterations in {el:.1f} s of the reference algorithm '
                 f'(dense-Kronecker element matrices as torch-CPU GEMMs on '
-                f'{torch.get_num_threads()} threads, stored J^-1 / detJ, '
+                f'{threads} threads, stored J^-1 / detJ, '
                 f'un-fused CG; a restatement, not JAX)',
   }
 
