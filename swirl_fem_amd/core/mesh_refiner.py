@@ -25,11 +25,32 @@ from swirl_fem_amd.core.interpolation import Nodes1D
 from swirl_fem_amd.core.premesh import Premesh
 
 
-def refine_premesh(premesh: Premesh, gridpoints_1d: Nodes1D) -> Premesh:
-  """Returns the p-refined premesh with `gridpoints_1d` nodes per direction."""
+def refine_premesh(premesh: Premesh, gridpoints_1d: Nodes1D, *,
+                   face_orientation: str = 'corrected') -> Premesh:
+  """Returns the p-refined premesh with `gridpoints_1d` nodes per direction.
+
+  Node numbering is the reference's (first-touch order, facets before element
+  interiors).  `face_orientation` selects how a facet that was already refined
+  by an earlier element is read back by a later one:
+
+  * `'corrected'` (default): the refined nodes are permuted by the orientation
+    of the later element's vertex ordering relative to the stored one.
+  * `'reference'`: the reference's lookup (core/mesh_refiner.py:213-217), which
+    builds the key from the *inverse* vertex permutation.  The two agree for
+    every orientation that is its own inverse -- all edge orientations, and
+    flips / transposes of faces, hence on structured and Gmsh-generated
+    meshes -- but for a face seen rotated by +-90 degrees the reference places
+    the face-interior nodes of the later element at the wrong positions (the
+    element no longer matches the multilinear map of its vertices;
+    `tests/test_host_logic.py::test_refiner_random_orientations`).  Kept for
+    bit-for-bit comparison with the reference's output.
+  """
   if premesh.order != 1:
     raise ValueError(f'Expecting mesh of order 1. Got {premesh.order}.')
-  return _BatchRefiner(premesh, gridpoints_1d).refine()
+  if face_orientation not in ('corrected', 'reference'):
+    raise ValueError(f'unknown face_orientation {face_orientation!r}')
+  return _BatchRefiner(premesh, gridpoints_1d,
+                       face_orientation == 'reference').refine()
 
 
 def _row_view(a: np.ndarray) -> np.ndarray:
@@ -81,8 +102,10 @@ class _FacetTable:
 
 class _BatchRefiner:
 
-  def __init__(self, premesh: Premesh, gridpoints_1d: Nodes1D):
+  def __init__(self, premesh: Premesh, gridpoints_1d: Nodes1D,
+               reference_keys: bool = False):
     self.premesh = premesh
+    self.reference_keys = reference_keys
     self.gridpoints_1d = gridpoints_1d
     self.num_points = gridpoints_1d.num_points
     self.interpolator = BarycentricInterpolator(
@@ -142,7 +165,10 @@ class _BatchRefiner:
         self._append_nodes(fcoords[is_new], num_new * m)
       # orientation of the current vertex ordering w.r.t. the stored one
       orient = table.orient[entry]                       # (nf, 2^k)
-      key = (curr[:, None, :] == orient[:, :, None]).argmax(axis=2)
+      if self.reference_keys:    # position of each stored vertex in `curr`
+        key = (curr[:, None, :] == orient[:, :, None]).argmax(axis=2)
+      else:                      # position of each vertex of `curr` in `orient`
+        key = (orient[:, None, :] == curr[:, :, None]).argmax(axis=2)
       base = 2 ** k
       code = key @ (base ** np.arange(base, dtype=np.int64))
       codes, perms = facet_util.orientation_table(k, p - 2)

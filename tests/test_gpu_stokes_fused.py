@@ -29,7 +29,24 @@ def relerr(a, b):
   return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def build(ndim, n, P, dtype, jitter=0.15, scramble=True, shear=False, seed=3):
+def reorient(pm, rng):
+  """Random element order and a random one of the 2^d d! orientations of the
+  reference cube per element (reflections give det J < 0), as the reference's
+  refiner tests do (core/mesh_refiner_test.py) and SURVEY config 3 asks."""
+  import itertools
+  d = pm.ndim
+  orients = [(perm, axes) for perm in itertools.permutations(range(d))
+             for r in range(d + 1)
+             for axes in itertools.combinations(range(d), r)]
+  new = []
+  for e in pm.elements[rng.permutation(pm.num_elements)]:
+    perm, axes = orients[rng.integers(len(orients))]
+    new.append(np.flip(e.reshape([2] * d).transpose(perm), axes).reshape(-1))
+  return pm.replace(elements=np.array(new, dtype=np.int32))
+
+
+def build(ndim, n, P, dtype, jitter=0.15, scramble=True, shear=False, seed=3,
+          orientations=False):
   rng = np.random.default_rng(seed)
   pm = unit_cube_mesh(n, ndim=ndim)
   x = pm.node_coords.copy()
@@ -38,7 +55,9 @@ def build(ndim, n, P, dtype, jitter=0.15, scramble=True, shear=False, seed=3):
   if jitter:
     x = x + jitter / n * rng.uniform(-1, 1, x.shape)
   pm = pm.replace(node_coords=x)
-  if scramble:
+  if orientations:
+    pm = reorient(pm, rng)
+  elif scramble:
     pm = pm.replace(elements=pm.elements[rng.permutation(pm.num_elements)])
   rv = refine_premesh(pm, Nodes1D.create(P, GLL))
   rq = refine_premesh(pm, Nodes1D.create(P - 2, GL))
@@ -93,6 +112,31 @@ def test_div_and_grad_t_match_oracle(ndim, n, P, dtype):
       rhs = float((free.grad_t(pd).double() * ud.double()).sum())
       assert abs(lhs - rhs) < (1e-11 if dtype == torch.float64 else 1e-4) * max(
           abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize('ndim,n,P', [(2, 4, 6), (3, 2, 5), (3, 2, 8)])
+def test_random_element_orientations(ndim, n, P):
+  """Unstructured connectivity: rotated and reflected elements (signed
+  Jacobians) through the cofactor kernels and the fused Helmholtz kernel."""
+  rng, vsp, psp, ov, op = build(ndim, n, P, torch.float64, jitter=0.2,
+                                orientations=True, seed=17)
+  assert (ov.jacdets < 0).any() and (ov.jacdets > 0).any()
+  mesh = vsp.mesh
+  bmask = mesh.physical_masks['boundary']
+  keep = (~bmask.cpu().numpy())
+  u = rng.standard_normal((mesh.num_nodes, ndim))
+  p = rng.standard_normal(psp.mesh.num_nodes)
+  d_ref = op.scatter(O.div_local(ov, op, ov.gather(u)))
+  g_ref = keep[:, None] * ov.scatter(O.div_t_local(ov, op, op.gather(p)))
+  ul = ov.gather(u)
+  h_ref = keep[:, None] * ov.scatter(0.6 * ov.mass_local(ul) +
+                                     1.2 * ov.stiffness_local(ul))
+  for geometry in ('auto', 'stored'):
+    fused = operators.StokesDivGrad.create(vsp, psp, bmask, geometry)
+    assert relerr(fused.div(dev(u)), d_ref) < 1e-10, geometry
+    assert relerr(fused.grad_t(dev(p)), g_ref) < 1e-10, geometry
+    helm = vsp.helmholtz_operator(bmask, geometry)
+    assert relerr(helm.apply(dev(u), 0.6, 1.2), h_ref) < 1e-10, geometry
 
 
 def test_mixed_geometry_kinds_and_eligibility():

@@ -155,8 +155,19 @@ def test_mesh_staging_matches_reference_goldens(golden_dir):
       pm = pm.replace(elements=scr['elements'])
     P = round(ref['elements'].shape[1] ** (1 / ndim))
     nt = 'gl' if re.search(r'_gl\d', name) else 'gll'
-    rp = refine_premesh(pm, I.Nodes1D.create(P, NT[nt]))
+    # bit-for-bit against the reference's own output (its facet lookup)
+    rp = refine_premesh(pm, I.Nodes1D.create(P, NT[nt]),
+                        face_orientation='reference')
     _cmp(_pmd(rp), ref, name + '/refined')
+    # the default differs only where the reference's output is geometrically
+    # inconsistent (faces met rotated by +-90 degrees; scrambled 3D cases)
+    rc = refine_premesh(pm, I.Nodes1D.create(P, NT[nt]))
+    np.testing.assert_allclose(rc.node_coords, rp.node_coords, atol=1e-14)
+    assert rc.elements.shape == rp.elements.shape
+    if not (scr and ndim == 3):
+      np.testing.assert_array_equal(rc.elements, rp.elements, err_msg=name)
+    else:
+      _assert_multilinear(pm, rc, I.Nodes1D.create(P, NT[nt]))
     arrs = rp.finalize_all('i')
     mine = dict(arrs, gather_indices=arrs['exchange_gather_indices'],
                 unique_indices=arrs['exchange_unique_indices'])
@@ -164,6 +175,64 @@ def test_mesh_staging_matches_reference_goldens(golden_dir):
       mine['local_nodes'] = arrs['global_node_ids']
       mine['local_elements'] = arrs['elements']
     _cmp(mine, fin, name + '/final')
+
+
+def _multilinear_error(pm, rp, nodes):
+  """Max distance of each refined element's nodes from the multilinear image
+  of its own 2^d vertices (in its own vertex ordering)."""
+  d = pm.ndim
+  t = (np.asarray(nodes.node_values) + 1) / 2
+  P = len(t)
+  xv = np.asarray(pm.node_coords)[np.asarray(pm.elements)].reshape(
+      (-1,) + (2,) * d + (d,))
+  out = np.zeros((len(xv),) + (P,) * d + (d,))
+  for corner in np.ndindex(*([2] * d)):
+    w = 1.0
+    for ax, c in enumerate(corner):
+      shape = [1] * d
+      shape[ax] = P
+      w = w * (t if c else 1 - t).reshape(shape)
+    out += w[None, ..., None] * xv[(slice(None),) + corner][
+        (slice(None),) + (None,) * d]
+  got = np.asarray(rp.node_coords)[np.asarray(rp.elements)]
+  return np.abs(got - out.reshape(len(xv), -1, d)).max(axis=(1, 2))
+
+
+def _assert_multilinear(pm, rp, nodes):
+  assert _multilinear_error(pm, rp, nodes).max() < 1e-12
+
+
+def test_refiner_random_orientations():
+  """Every one of the 2^d d! vertex orderings per element (random mix, random
+  element order): the refined elements are the multilinear images of their
+  vertices.  The reference's facet lookup fails this for faces met rotated by
+  +-90 degrees (see `refine_premesh`), the default lookup does not."""
+  import itertools
+  rng = np.random.default_rng(0)
+  nodes = I.Nodes1D.create(4, NT['gll'])
+  for ndim, n in ((2, 3), (3, 2)):
+    base = unit_cube_mesh(n, ndim=ndim)
+    x = base.node_coords + 0.1 / n * rng.uniform(-1, 1, base.node_coords.shape)
+    orients = [(perm, axes) for perm in itertools.permutations(range(ndim))
+               for r in range(ndim + 1)
+               for axes in itertools.combinations(range(ndim), r)]
+    bad_reference = 0
+    for _ in range(25):
+      el = []
+      for e in base.elements[rng.permutation(base.num_elements)]:
+        perm, axes = orients[rng.integers(len(orients))]
+        el.append(np.flip(e.reshape([2] * ndim).transpose(perm),
+                          axes).reshape(-1))
+      pm = base.replace(node_coords=x, elements=np.array(el, dtype=np.int32))
+      rp = refine_premesh(pm, nodes)
+      _assert_multilinear(pm, rp, nodes)
+      rr = refine_premesh(pm, nodes, face_orientation='reference')
+      assert rr.num_nodes == rp.num_nodes
+      bad_reference += int((_multilinear_error(pm, rr, nodes) > 1e-9).sum())
+    if ndim == 2:
+      assert bad_reference == 0       # edges: every orientation is an involution
+    else:
+      assert bad_reference > 0        # documents the upstream defect
 
 
 def test_unit_cube_mesh_counts():
