@@ -75,10 +75,14 @@ struct HelmholtzTile {
   static constexpr int SA = DIM == 3 ? P * SB : SB;      // axis-0 stride
   static constexpr int ELEM_WORDS = P * SA;              // one padded tensor
   static constexpr int LDS_PER_ELEM = 2 * ELEM_WORDS * (int)sizeof(T);
-  // elements per workgroup: fill whole waves, stay under ~40 KiB of LDS and
-  // 512 threads; a single wave when an element divides a wave evenly.
+  // elements per workgroup (TPE < 64): fill whole waves, stay under ~40 KiB of
+  // LDS and 512 threads; a single wave when an element divides a wave evenly.
   static constexpr int pick_epb() {
     if (64 % TPE == 0) return 64 / TPE;
+    // An element that already spans several waves gets its own workgroup:
+    // packing two (P = 12: 288 of 320 lanes) fills lanes better but couples 5
+    // waves at every barrier; measured 26-32 % slower (p = 9, 11 fp32).
+    if (TPE > 64) return 1;
     int best = 1;
     double best_util = 0.0;
     for (int epb = 1; epb <= 16; ++epb) {
