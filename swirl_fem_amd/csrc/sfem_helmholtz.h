@@ -79,6 +79,10 @@ struct HelmholtzTile {
   // LDS and 512 threads; a single wave when an element divides a wave evenly.
   static constexpr int pick_epb() {
     if (64 % TPE == 0) return 64 / TPE;
+    // More than half a wave (P = 6, 7 in 3D): one element per one-wave
+    // workgroup -- idle lanes cost less than barriers across 4-7 waves
+    // (measured +13..24 % at p = 5, 6).
+    if (2 * TPE > 64 && TPE < 64) return 1;
     // An element that already spans several waves gets its own workgroup:
     // packing two (P = 12: 288 of 320 lanes) fills lanes better but couples 5
     // waves at every barrier; measured 26-32 % slower (p = 9, 11 fp32).
