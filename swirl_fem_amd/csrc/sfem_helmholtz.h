@@ -58,7 +58,6 @@ struct HelmholtzParams {
   int64_t comp_stride;   //                           component * comp_stride
   int comp;              // first component
   T lambda0, lambda1;
-  int debug_flags;       // reserved for A/B experiments (SFEM_DEBUG_FLAGS)
   double* dot_out;       // SFEM_DOT_SLOTS partial sums of u . out, or null
   int colored;           // launches are conflict-free colour classes: SHARED
                          // slots read-modify-write instead of atomics
@@ -177,17 +176,6 @@ __device__ __forceinline__ void line_apply(const DMat<T, P>& dm,
       y[r] = so;
     }
   }
-}
-
-// XCD-aware block -> work-group-of-elements map: blocks b and b+8 share an
-// XCD (and its L2), so give every XCD one contiguous range of the mesh; the
-// faces shared by consecutive elements are then re-read from the same L2.
-__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nblocks) {
-  const int64_t per = nblocks / 8, rem = nblocks % 8;
-  const int64_t x = b % 8, k = b / 8;
-  // XCD x owns `per + (x < rem)` consecutive groups
-  const int64_t start = x * per + (x < rem ? x : rem);
-  return start + k;
 }
 
 // Geometry modes.  The symmetric factors G = w detJ (J^-1 J^-T) (and W = w detJ)

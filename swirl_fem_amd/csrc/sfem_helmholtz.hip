@@ -135,7 +135,6 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
   prm.node_stride = c.node_stride > 0 ? c.node_stride : c.ncomp;
   prm.comp_stride = c.node_stride > 0 ? c.comp_stride : 1;
   prm.comp = 0; prm.lambda0 = (T)c.l0; prm.lambda1 = (T)c.l1;
-  prm.debug_flags = 0;
   prm.dot_out = c.dot_out;
   prm.colored = c.colored;
   if (c.ndim == 3) return dispatch_helmholtz<T, 3>(prm, c.P, c.gs, stream);

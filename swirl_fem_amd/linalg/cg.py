@@ -8,7 +8,7 @@ returns `(x, {'residual', 'num_iterations'})`.
 The reference keeps the loop on the device with `lax.while_loop` (:94-95).
 Here the five scalars of the recurrence live in a small device array and every
 vector update is a fused HIP kernel that reads them there (`sfem_dot*`,
-`sfem_cg_update_xr`, `sfem_cg_update_p`, `sfem_cg_scalars`), so an iteration
+`sfem_cg_update_r`, `sfem_cg_update_xp`, `sfem_cg_scalars`), so an iteration
 issues no host synchronisation.  The stopping test is evaluated on the device
 each iteration; once it fires every later kernel is a no-op, and the host only
 polls the flag every `check_every` iterations.  Iterates and iteration count

@@ -658,6 +658,37 @@ def test_cg_with_fused_operator_dot():
 
 
 # ------------------------------------------------------------------ Poisson
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_cg_update_groupings_agree(dtype):
+  """9-pass (xr, p) and 8-pass (r, xp) groupings of the CG vector updates are
+  the same arithmetic; odd lengths exercise the scalar tails."""
+  from swirl_fem_amd import _ops
+  g = torch.Generator(device=DEV).manual_seed(3)
+  for n in (1, 7, 1000, 100003):
+    v = [torch.randn(n, dtype=dtype, device=DEV, generator=g) for _ in range(4)]
+    s = torch.zeros(16, dtype=torch.float64, device=DEV)
+    s[0], s[1] = 2.5, 1.7                      # gamma, p.Ap -> alpha = gamma / pAp
+    for fuse in (True, False):
+      x1, r1, p1, ap = (t.clone() for t in v)
+      x2, r2, p2 = x1.clone(), r1.clone(), p1.clone()
+      s1, s2 = s.clone(), s.clone()
+      _ops.cg_update_xr(x1, r1, p1, ap, s1, fuse)
+      _ops.cg_update_r(r2, ap, s2, fuse)
+      if not fuse:                              # gamma_new from a separate dot
+        s1[2] = s2[2] = float((r1.double() ** 2).sum())
+      _ops.cg_update_p(p1, r1, s1)
+      _ops.cg_update_xp(x2, p2, r2, s2)
+      tol = 1e-14 if dtype == torch.float64 else 1e-6
+      assert torch.equal(r1, r2) and torch.equal(x1, x2)
+      # beta = gamma_new / gamma: the fused r.r is summed by atomics, so its
+      # last bits (and with them p) depend on the arrival order
+      assert float((p1 - p2).abs().max()) <= 100 * tol * float(p1.abs().max())
+      alpha = 2.5 / 1.7
+      assert float((x1 - (v[0] + alpha * v[2])).abs().max()) < tol * 10
+      assert abs(float(s1[2]) - float((r1.double() ** 2).sum())) < 1e-9 * n
+      assert float(s1[2]) == float(s2[2]) or fuse   # atomics: order may differ
+
+
 def test_cg_graph_replay_matches_eager():
   """One HIP graph launch per iteration == the eager launch sequence."""
   from swirl_fem_amd.linalg.cg import cg, CGRunner
