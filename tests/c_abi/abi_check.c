@@ -1,0 +1,149 @@
+/* Plain-C client of include/sfem.h: no Python, no torch -- only the HIP
+ * runtime for device memory.  Built and run by tests/test_c_abi.py.
+ *
+ * Checks, on one affine hex element of P^3 GLL nodes scaled to [0,h]^3:
+ *   gather / scatter-add round trip with a -1 sentinel,
+ *   stiffness of a constant = 0, mass of a constant sums to the volume,
+ *   sfem_dot, error reporting through sfem_last_error().
+ * Exit code 0 = all good; prints the failing check otherwise. */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sfem.h"
+
+#define CHECK(cond, ...)                       \
+  do {                                         \
+    if (!(cond)) {                             \
+      fprintf(stderr, "FAIL: " __VA_ARGS__);   \
+      fprintf(stderr, "\n");                   \
+      return 1;                                \
+    }                                          \
+  } while (0)
+#define HIP(call) CHECK((call) == hipSuccess, #call)
+
+static void* to_device(const void* src, size_t bytes) {
+  void* d = NULL;
+  if (hipMalloc(&d, bytes) != hipSuccess) return NULL;
+  if (src && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    return NULL;
+  return d;
+}
+
+int main(void) {
+  CHECK(sfem_abi_version() == SFEM_ABI_VERSION, "ABI version");
+
+  /* --- gather / scatter-add with the -1 sentinel (gather_scatter.py:121-133) */
+  {
+    const double u[4] = {1.0, 2.0, 3.0, 4.0};
+    const int32_t idx[6] = {0, 3, -1, 3, 1, 0};
+    double got[6], back[4];
+    double* du = (double*)to_device(u, sizeof u);
+    int32_t* di = (int32_t*)to_device(idx, sizeof idx);
+    double* dl = (double*)to_device(NULL, sizeof got);
+    double* db = (double*)to_device(NULL, sizeof back);
+    CHECK(du && di && dl && db, "hipMalloc");
+    CHECK(sfem_gather(du, di, dl, 6, -7.0, SFEM_F64, NULL) == SFEM_OK, "%s",
+          sfem_last_error());
+    HIP(hipMemcpy(got, dl, sizeof got, hipMemcpyDeviceToHost));
+    const double want[6] = {1.0, 4.0, -7.0, 4.0, 2.0, 1.0};
+    for (int i = 0; i < 6; ++i) CHECK(got[i] == want[i], "gather[%d]", i);
+    CHECK(sfem_gather(du, di, dl, 6, 0.0, SFEM_F64, NULL) == SFEM_OK, "gather");
+    CHECK(sfem_scatter_add(dl, di, db, 6, 4, 1, SFEM_F64, NULL) == SFEM_OK, "%s",
+          sfem_last_error());
+    HIP(hipMemcpy(back, db, sizeof back, hipMemcpyDeviceToHost));
+    const double sums[4] = {2.0, 2.0, 0.0, 8.0};
+    for (int i = 0; i < 4; ++i) CHECK(back[i] == sums[i], "scatter[%d]", i);
+    double* dres = (double*)to_device(NULL, sizeof(double));
+    double res = 0.0;
+    CHECK(sfem_dot(du, du, 4, dres, SFEM_F64, NULL) == SFEM_OK, "dot");
+    HIP(hipMemcpy(&res, dres, sizeof res, hipMemcpyDeviceToHost));
+    CHECK(res == 30.0, "dot = %g", res);
+    /* invalid arguments come back as a status + message, never a crash */
+    CHECK(sfem_gather(du, di, dl, -1, 0.0, SFEM_F64, NULL) != SFEM_OK, "bad count");
+    CHECK(strlen(sfem_last_error()) > 0, "error message");
+  }
+
+  /* --- fused Helmholtz apply on one affine element, P = 4 GLL nodes --------- */
+  {
+    enum { P = 4, N = P * P * P };
+    const double h = 0.5;
+    const double s5 = sqrt(0.2);
+    const double x1[P] = {-1.0, -s5, s5, 1.0};              /* GLL nodes    */
+    const double w1[P] = {1.0 / 6, 5.0 / 6, 5.0 / 6, 1.0 / 6};
+    /* barycentric differentiation matrix on x1 (interpolation.py:230-244) */
+    double bw[P], D[P * P];
+    for (int i = 0; i < P; ++i) {
+      bw[i] = 1.0;
+      for (int j = 0; j < P; ++j)
+        if (j != i) bw[i] /= (x1[i] - x1[j]);
+    }
+    for (int i = 0; i < P; ++i) {
+      double row = 0.0;
+      for (int j = 0; j < P; ++j)
+        if (j != i) {
+          D[i * P + j] = (bw[j] / bw[i]) / (x1[i] - x1[j]);
+          row += D[i * P + j];
+        }
+      D[i * P + i] = -row;
+    }
+    double coords[N * 3], ones[N], lin[N], out[N];
+    int32_t elems[N];
+    for (int a = 0; a < P; ++a)
+      for (int b = 0; b < P; ++b)
+        for (int c = 0; c < P; ++c) {
+          const int k = (a * P + b) * P + c;
+          coords[3 * k + 0] = h * (x1[a] + 1) / 2;
+          coords[3 * k + 1] = h * (x1[b] + 1) / 2;
+          coords[3 * k + 2] = h * (x1[c] + 1) / 2;
+          ones[k] = 1.0;
+          lin[k] = coords[3 * k + 0];                       /* u = x         */
+          elems[k] = k;
+        }
+    double* dco = (double*)to_device(coords, sizeof coords);
+    double* dge = (double*)to_device(NULL, 24 * sizeof(double));
+    int32_t* del = (int32_t*)to_device(elems, sizeof elems);
+    int32_t* den = (int32_t*)to_device(NULL, sizeof elems);
+    int32_t mult[N];
+    for (int k = 0; k < N; ++k) mult[k] = 1;
+    int32_t* dmu = (int32_t*)to_device(mult, sizeof mult);
+    double* du1 = (double*)to_device(ones, sizeof ones);
+    double* dux = (double*)to_device(lin, sizeof lin);
+    double* dout = (double*)to_device(NULL, sizeof out);
+    CHECK(dco && dge && del && den && dmu && du1 && dux && dout, "hipMalloc");
+    CHECK(sfem_helmholtz_setup_multilinear(dco, dge, 1, 3, P, SFEM_F64, NULL) ==
+              SFEM_OK, "%s", sfem_last_error());
+    CHECK(sfem_encode_elements(del, NULL, dmu, NULL, den, N, NULL) == SFEM_OK,
+          "%s", sfem_last_error());
+    sfem_helmholtz_args a;
+    memset(&a, 0, sizeof a);
+    a.out = dout; a.enc = den; a.geo_elem = dge;
+    a.dmat = D; a.weights = w1; a.nodes = x1;
+    a.num_elements = 1; a.num_nodes = N; a.ndim = 3; a.P = P; a.ncomp = 1;
+    a.dtype = SFEM_F64; a.geo_mode = SFEM_GEO_AFFINE;
+    /* stiffness of a constant vanishes */
+    a.u = du1; a.lambda0 = 0.0; a.lambda1 = 1.0;
+    CHECK(sfem_helmholtz_apply(&a, NULL) == SFEM_OK, "%s", sfem_last_error());
+    HIP(hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost));
+    for (int k = 0; k < N; ++k) CHECK(fabs(out[k]) < 1e-13, "A 1 [%d] = %g", k, out[k]);
+    /* mass of a constant sums to the volume h^3 */
+    a.lambda0 = 1.0; a.lambda1 = 0.0;
+    CHECK(sfem_helmholtz_apply(&a, NULL) == SFEM_OK, "%s", sfem_last_error());
+    HIP(hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost));
+    double vol = 0.0;
+    for (int k = 0; k < N; ++k) vol += out[k];
+    CHECK(fabs(vol - h * h * h) < 1e-14, "sum B 1 = %.17g", vol);
+    /* u = x:  x^T A x = int |grad x|^2 = h^3 */
+    a.u = dux; a.lambda0 = 0.0; a.lambda1 = 1.0;
+    CHECK(sfem_helmholtz_apply(&a, NULL) == SFEM_OK, "%s", sfem_last_error());
+    HIP(hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost));
+    double energy = 0.0;
+    for (int k = 0; k < N; ++k) energy += lin[k] * out[k];
+    CHECK(fabs(energy - h * h * h) < 1e-14, "x^T A x = %.17g", energy);
+  }
+  HIP(hipDeviceSynchronize());
+  printf("c-abi OK\n");
+  return 0;
+}
