@@ -777,7 +777,7 @@ def test_poisson_reference_1d_and_circle():
 
 
 # -------------------------------------------- full-size properties (config 2)
-@pytest.mark.parametrize('n', [int(os.environ.get('SFEM_TEST_FULL_N', '32'))])
+@pytest.mark.parametrize('n', [int(os.environ.get('SFEM_TEST_FULL_N', '64'))])
 def test_config2_properties_full_size(n):
   """3D p=7 Laplacian at bench scale: symmetry, nullspace, linearity,
   fused == generic path, assembled == deterministic assembly."""
@@ -816,3 +816,26 @@ def test_config2_properties_full_size(n):
   assert float((det - Au).abs().max()) < 1e-10 * scale
   loc2 = op.apply_local(mesh.gather(u), 0.0, 1.0)
   assert float((loc2 - loc).abs().max()) < 1e-10 * float(loc.abs().max())
+  del loc, loc2, gen, det, uf
+  # stored-factor path == on-the-fly geometry; fused p.Ap == dot(p, Ap)
+  op_s = fes.helmholtz_operator(None, 'stored')
+  assert float((op_s.apply(u) - Au).abs().max()) < 1e-10 * scale
+  from swirl_fem_amd import _lib
+  parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64, device=DEV)
+  op.apply(u, dot_out=parts)
+  ref = float(torch.dot(u, Au))
+  assert abs(float(parts.sum()) - ref) < 1e-10 * abs(ref)
+  # a few CG iterations reduce the energy-norm error monotonically: solve
+  # A x = A x* on the Dirichlet problem and watch |x - x*|_A
+  bm = mesh.physical_masks['boundary']
+  op_d = fes.helmholtz_operator(bm)
+  xs = u * (~bm)
+  from swirl_fem_amd.linalg.cg import CGRunner
+  run = CGRunner(op_d.linear_operator(0.0, 1.0), op_d.apply(xs), tol=0.0,
+                 maxiter=10 ** 6)
+  errs = []
+  for _ in range(6):
+    run.step()
+    e = run.x - xs
+    errs.append(float(torch.dot(e, op_d.apply(e))))
+  assert all(b < a for a, b in zip(errs, errs[1:])), errs

@@ -189,3 +189,43 @@ def test_stokes_sem_uses_fused_kernels_and_matches_generic(ndim, order):
   assert rel(sem.D(u), generic.D(u)) < 1e-11
   assert rel(sem.Dt(p), generic.Dt(p)) < 1e-11
   assert rel(sem.E(p, 1e-3, 3), generic.E(p, 1e-3, 3)) < 1e-10
+
+
+def test_stokes_properties_at_scale():
+  """32^3 elements, p = 7 (1/8 of a config-4 GPU block): D and D^T are
+  adjoint, E = D Q D^T is symmetric positive semi-definite, constants are in
+  the kernel of D^T's pressure side only through the boundary."""
+  ndim, n, P = 3, 32, 8
+  pm = unit_cube_mesh(n, ndim=ndim)
+  rng = np.random.default_rng(9)
+  pm = pm.replace(node_coords=pm.node_coords + 0.15 / n * rng.uniform(
+      -1, 1, pm.node_coords.shape))
+  quad = Quadrature1D.create(P, GLL)
+  vsp = FiniteElementSpace.create(
+      refine_premesh(pm, Nodes1D.create(P, GLL)).finalize(device=DEV), quad)
+  psp = FiniteElementSpace.create(
+      refine_premesh(pm, Nodes1D.create(P - 2, GL)).finalize(device=DEV), quad)
+  bmask = vsp.mesh.physical_masks['boundary']
+  free = operators.StokesDivGrad.create(vsp, psp, None)
+  masked = operators.StokesDivGrad.create(vsp, psp, bmask)
+  g = torch.Generator(device=DEV).manual_seed(1)
+  u = torch.randn(vsp.mesh.num_nodes, ndim, dtype=torch.float64, device=DEV,
+                  generator=g)
+  p = torch.randn(psp.mesh.num_nodes, dtype=torch.float64, device=DEV,
+                  generator=g)
+  q = torch.randn(psp.mesh.num_nodes, dtype=torch.float64, device=DEV,
+                  generator=g)
+  lhs, rhs = float(torch.dot(free.div(u), p)), float((free.grad_t(p) * u).sum())
+  assert abs(lhs - rhs) < 1e-10 * abs(lhs)
+  # divergence theorem: int div(u) = 0 for u vanishing on the boundary, i.e.
+  # the masked D^T maps the constant pressure to zero
+  ones = torch.ones_like(p)
+  assert float(masked.grad_t(ones).abs().max()) < 1e-10 * float(
+      masked.grad_t(p).abs().max())
+  scale = torch.rand(vsp.mesh.num_nodes, 1, dtype=torch.float64, device=DEV,
+                     generator=g).expand(-1, ndim) + 0.5
+  E = lambda x: masked.div(masked.grad_t(x, component_major=True), scale=scale)
+  Ep, Eq = E(p), E(q)
+  a, b = float(torch.dot(Ep, q)), float(torch.dot(p, Eq))
+  assert abs(a - b) < 1e-9 * abs(a)
+  assert float(torch.dot(Ep, p)) > 0
