@@ -160,9 +160,6 @@ class FiniteElementSpace:
   mesh: Mesh
   quadrature: Quadrature1D
   interpolator: BarycentricInterpolator
-  invjacs: torch.Tensor
-  jacdets: torch.Tensor
-  quad_coords: torch.Tensor
   _cache: dict = dataclasses.field(default_factory=dict, repr=False,
                                    compare=False)
 
@@ -171,15 +168,34 @@ class FiniteElementSpace:
     interpolator = BarycentricInterpolator(
         ndim=mesh.ndim, gridpoints_1d=mesh.gridpoints_1d,
         evalpoints_1d=quadrature.nodes)
-    cache = {}
-    i1, g1 = _device_matrices(interpolator, mesh.dtype, mesh.device, cache)
-    elem_coords = mesh.element_coords()
-    invjacs, jacdets, quad_coords = _ops.geom_factors(
-        elem_coords, i1, g1, mesh.ndim, mesh.gridpoints_1d.num_points,
-        quadrature.num_points, want_quad_coords=True)
     return cls(mesh=mesh, quadrature=quadrature, interpolator=interpolator,
-               invjacs=invjacs, jacdets=jacdets, quad_coords=quad_coords,
-               _cache=cache)
+               _cache={})
+
+  # The reference computes and stores `invjacs (E,Q,d,d)`, `jacdets (E,Q)` and
+  # `quad_coords (E,Q,d)` in `create` (core/fespace.py:330-348): 13 reals per
+  # quadrature point, 14 GB at 64^3 elements / p = 7.  Here they are built on
+  # first use (one `sfem_geom_factors` launch): the fused operators evaluate
+  # the geometry of multilinear elements in registers and never ask for them.
+  def _geometry(self):
+    if 'geometry' not in self._cache:
+      i1, g1 = self._matrices()
+      self._cache['geometry'] = _ops.geom_factors(
+          self.mesh.element_coords(), i1, g1, self.mesh.ndim,
+          self.mesh.gridpoints_1d.num_points, self.quadrature.num_points,
+          want_quad_coords=True)
+    return self._cache['geometry']
+
+  @property
+  def invjacs(self) -> torch.Tensor:
+    return self._geometry()[0]
+
+  @property
+  def jacdets(self) -> torch.Tensor:
+    return self._geometry()[1]
+
+  @property
+  def quad_coords(self) -> torch.Tensor:
+    return self._geometry()[2]
 
   def replace(self, **kw):
     kw.setdefault('_cache', {})
@@ -196,11 +212,11 @@ class FiniteElementSpace:
 
   @property
   def dtype(self):
-    return self.jacdets.dtype
+    return self.mesh.dtype
 
   @property
   def device(self):
-    return self.jacdets.device
+    return self.mesh.device
 
   @property
   def is_collocated(self) -> bool:
