@@ -17,6 +17,8 @@ CASES = {
                   name='3D Taylor-Green, 16^3 hexes, p=7, triply periodic'),
     'tgv32': dict(fn='taylor_green', kw=dict(n=32, order=7, reynolds=1600.0, dt=1e-3, steps=4, tol=1e-6),
                   name='3D Taylor-Green, 32^3 hexes, p=7, triply periodic (1/8 of a config-4 GPU block)'),
+    'tgv64': dict(fn='taylor_green', kw=dict(n=64, order=7, reynolds=1600.0, dt=1e-3, steps=3, tol=1e-6),
+                  name='3D Taylor-Green, 64^3 hexes, p=7, triply periodic (one config-4 GPU block)'),
 }
 for key in (sys.argv[1:] or ['cavity', 'tgv16']):
   c = CASES[key]; prof = {}
