@@ -252,7 +252,7 @@ int sfem_helmholtz_local(const sfem_helmholtz_args* args, sfem_stream_t stream);
  *
  *   sfem_stokes_div:     p_out = pressure.scatter(D_local(velocity.gather(s u)))
  *       D_local(u)_k = sum_q phi_k(x_q) w_q detJ_q div u(x_q)          (:313-320)
- *       `scale` (optional, same layout as u) multiplies u node by node as it is
+ *       `scale` (optional; same layout as u, or one value per node) multiplies u as it is
  *       gathered: E = D Q D^T applies Q = (dt/beta_k) B^-1 (:340-348) for free.
  *   sfem_stokes_grad_t:  out = mask * velocity.scatter(Dt_local(pressure.gather(p)))
  *       Dt_local(p)_{i,c} = sum_q w_q detJ_q p(x_q) d phi_i/d x_c      (:322-338)
@@ -272,7 +272,8 @@ typedef struct sfem_stokes_args {
   void* out;              /* grad_t: (N, ndim) result                          */
   const void* p_in;       /* grad_t: (Np,) pressure                            */
   void* p_out;            /* div: (Np,) result                                 */
-  const void* scale;      /* div: optional (N, ndim) per-node factor, or NULL  */
+  const void* scale;      /* div: optional per-node factor, or NULL: (N, ndim)
+                             in the layout of u, or (N,) if scale_per_node   */
   const int32_t* enc;     /* (E, n) encoded velocity indices                   */
   const int32_t* penc;    /* (E, np) pressure node ids or NULL                 */
   const void* kfac;       /* per-point weighted cofactors or NULL              */
@@ -290,6 +291,7 @@ typedef struct sfem_stokes_args {
   int32_t ndim, P, dtype, geo_mode;
   int64_t node_stride, comp_stride;  /* layout of u / out / scale (0 = (N, ndim)
                                         row-major)                             */
+  int32_t scale_per_node; /* scale is one (N,) factor shared by the components */
 } sfem_stokes_args;
 
 int sfem_stokes_setup(const void* invjac, const void* jacdet,

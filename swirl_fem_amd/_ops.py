@@ -429,16 +429,22 @@ def stokes_div(u, p_out, enc, penc, parts, host, ndim, P, scale=None):
   geometry kind."""
   dev = _dev(enc, p_out)
   _check_field(u, ndim)
-  if scale is not None:
+  per_node = scale is not None and scale.dim() == 1
+  if per_node:
+    if scale.shape[0] != u.shape[0] or not scale.is_contiguous():
+      raise ValueError('per-node scale must be a contiguous (N,) vector')
+  elif scale is not None:
     _check_field(scale, ndim)
-    if scale.stride() != u.stride() or scale.dtype != u.dtype:
-      raise ValueError('scale must share layout and dtype with u')
+    if scale.stride() != u.stride():
+      raise ValueError('scale must share the layout of u')
+  if scale is not None and scale.dtype != u.dtype:
+    raise ValueError('scale must share the dtype of u')
   host = {k: _host(v, u.dtype) for k, v in host.items()}
   with torch.cuda.device(dev):
     for part in parts:
       args = _stokes_args(u, enc, penc, part, host, ndim, P, (0, 0),
                           u=u.data_ptr(), p_out=p_out.data_ptr(),
-                          scale=_dptr(scale))
+                          scale=_dptr(scale), scale_per_node=int(per_node))
       _lib.check(_lib.load().sfem_stokes_div(ctypes.byref(args), _stream(dev)),
                  'sfem_stokes_div')
   return p_out

@@ -374,7 +374,7 @@ class StokesDivGrad:
                num_pressure_nodes=pspace.mesh.num_nodes)
 
   def div(self, u, scale=None, out=None):
-    """(N, d) -> (Np,):  D (scale * u)."""
+    """(N, d) -> (Np,):  D (scale * u); `scale` is (N, d) or (N,)."""
     mesh = self.vspace.mesh
     if tuple(u.shape) != (mesh.num_nodes, mesh.ndim):
       raise ValueError(f'expected ({mesh.num_nodes}, {mesh.ndim}) velocity, '
@@ -383,7 +383,11 @@ class StokesDivGrad:
     if not (u.is_contiguous() or _ops.is_component_major(u)):
       u = u.contiguous()
     if scale is not None:
-      scale = _like_layout(scale.to(u.dtype).expand_as(u), u)
+      scale = scale.to(u.dtype)
+      if scale.dim() == 1:           # one factor per node for all components
+        scale = scale.contiguous()
+      else:
+        scale = _like_layout(scale.expand_as(u), u)
     if out is None:
       # pressure nodes that no element references (none on refiner meshes)
       out = (torch.empty if self.penc is None else torch.zeros)(

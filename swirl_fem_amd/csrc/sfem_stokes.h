@@ -44,6 +44,7 @@ struct StokesParams {
   int64_t num_elements;
   int geo_mode;
   int64_t node_stride, comp_stride;
+  int64_t scale_node_stride, scale_comp_stride;   // comp stride 0: one factor per node
 };
 
 // Pressure-basis values at the velocity points, by value in the kernel
@@ -272,7 +273,9 @@ stokes_div_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
       T v = T(0);
       if (id != SFEM_IDX_PAD) {
         v = prm.u[(int64_t)id * ns + c * ks];
-        if (prm.scale) v *= prm.scale[(int64_t)id * ns + c * ks];
+        if (prm.scale)
+          v *= prm.scale[(int64_t)id * prm.scale_node_stride +
+                         c * prm.scale_comp_stride];
       }
       ua[a] = v;
     }

@@ -41,6 +41,13 @@ static int run_stokes(const sfem_stokes_args* a, bool grad_t,
   prm.geo_mode = a->geo_mode;
   prm.node_stride = a->node_stride > 0 ? a->node_stride : a->ndim;
   prm.comp_stride = a->node_stride > 0 ? a->comp_stride : 1;
+  if (a->scale_per_node) {
+    prm.scale_node_stride = 1;
+    prm.scale_comp_stride = 0;
+  } else {
+    prm.scale_node_stride = prm.node_stride;
+    prm.scale_comp_stride = prm.comp_stride;
+  }
   if (a->ndim == 3) return dispatch_stokes<T, 3>(prm, a->P, grad_t, stream);
   return dispatch_stokes<T, 2>(prm, a->P, grad_t, stream);
 }

@@ -99,6 +99,9 @@ def test_div_and_grad_t_match_oracle(ndim, n, P, dtype):
       ud, pd = dev(u, dtype), dev(p, dtype)
       assert relerr(fused.div(ud), d_ref) < tol, (geometry, shear)
       assert relerr(fused.div(ud, scale=dev(sc, dtype)), ds_ref) < tol
+      s1 = np.ascontiguousarray(sc[:, 0])
+      d1_ref = op.scatter(O.div_local(ov, op, ov.gather(s1[:, None] * u)))
+      assert relerr(fused.div(ud, scale=dev(s1, dtype)), d1_ref) < tol
       assert relerr(fused.grad_t(pd), g_ref) < tol, (geometry, shear)
       # component-major storage of the velocity-sized fields
       ucm = layout.component_major(ud)
