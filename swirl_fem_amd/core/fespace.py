@@ -335,8 +335,15 @@ class FiniteElementSpace:
     key = ('helmholtz', None if dirichlet_mask is None else id(dirichlet_mask),
            geometry, assembly)
     if key not in self._cache:
-      self._cache[key] = operators.HelmholtzOperator.create(
-          self, dirichlet_mask, geometry, assembly)
+      if not self.is_collocated and assembly == 'atomic' and (
+          operators.supports_two_grid(self) is None):
+        # quadrature != nodes: interpolate, fused element kernel on the
+        # quadrature grid, transposed interpolation
+        self._cache[key] = operators.TwoGridHelmholtzOperator.create(
+            self, dirichlet_mask, 'stored' if geometry == 'stored' else 'auto')
+      else:
+        self._cache[key] = operators.HelmholtzOperator.create(
+            self, dirichlet_mask, geometry, assembly)
     return self._cache[key]
 
 

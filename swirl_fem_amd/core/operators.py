@@ -422,3 +422,144 @@ def _like_layout(t, ref):
   out = torch.empty_like(ref)        # preserves the dense layout of ref
   out.copy_(t)
   return out
+
+
+# ---------------------------------------------------------------------------
+# Helmholtz operator with a quadrature that differs from the nodes
+# ---------------------------------------------------------------------------
+def supports_two_grid(fespace) -> str | None:
+  """None if `TwoGridHelmholtzOperator` applies, else the reason."""
+  mesh = fespace.mesh
+  q = fespace.quadrature.num_points
+  if mesh.ndim not in (2, 3):
+    return f'ndim={mesh.ndim}'
+  if not 2 <= q <= MAX_FUSED_P:
+    return f'q={q} outside 2..{MAX_FUSED_P}'
+  d = _quadrature_dmat(fespace)
+  if not np.allclose(d[::-1, ::-1], -d, rtol=0,
+                     atol=1e-12 * max(1.0, np.abs(d).max())):
+    return 'quadrature points are not symmetric about 0'
+  return None
+
+
+def _quadrature_dmat(fespace):
+  """Differentiation matrix of the Lagrange basis ON the quadrature points."""
+  from swirl_fem_amd.core.interpolation import BarycentricInterpolator
+  qn = fespace.quadrature.nodes
+  return BarycentricInterpolator(ndim=fespace.mesh.ndim, gridpoints_1d=qn,
+                                 evalpoints_1d=qn)._differentiation_matrix_1d()
+
+
+@dataclasses.dataclass(eq=False)
+class TwoGridHelmholtzOperator:
+  """`mask * scatter((l0 B + l1 A)_local(gather(u)))` when the quadrature is
+  not the node set (the reference's Poisson example integrates with
+  `order + (ndim+1)//2` Gauss points, examples/poisson.py:112-114).
+
+  With I the (Q, n) interpolation to the quadrature points,
+  `A_local = I^T A_q I` where `A_q` is the *collocated* operator of the
+  Lagrange basis on the quadrature points (the gradient of the interpolant is
+  exact there because q >= P).  So the element work is: interpolate
+  (`sfem_basis_eval`), the fused element-local kernel on the q-grid
+  (`sfem_helmholtz_local` with the q-point differentiation matrix, weights and
+  nodes; geometry of multilinear elements evaluated in registers), transposed
+  interpolation (`sfem_basis_eval_t`).  Replaces the generic chain basis_eval
+  (values + physical gradients) -> pointwise form -> basis_eval_t."""
+  fespace: object
+  parts: list
+  host: dict
+  mask: torch.Tensor | None        # (N,) 1 inside, 0 on Dirichlet nodes
+
+  @classmethod
+  def create(cls, fespace, dirichlet_mask=None,
+             geometry='auto') -> 'TwoGridHelmholtzOperator':
+    why = supports_two_grid(fespace)
+    if why is not None:
+      raise NotImplementedError(f'two-grid Helmholtz unavailable: {why}')
+    if geometry not in ('auto', 'stored'):
+      raise ValueError(f'unknown geometry mode {geometry!r}')
+    mesh = fespace.mesh
+    E, dev = mesh.num_elements, fespace.device
+    w = torch.as_tensor(fespace.quadrature.weights_nd(mesh.ndim),
+                        dtype=fespace.dtype, device=dev)
+    from swirl_fem_amd.core.interpolation import NodeType
+    corners = mesh.gridpoints_1d.node_type in (
+        NodeType.GAUSS_LOBATTO_LEGENDRE, NodeType.NEWTON_COTES)
+    if geometry == 'stored' or not corners:
+      kind = torch.zeros(E, dtype=torch.int32, device=dev)
+      coef = None
+    else:
+      kind, coef = classify_geometry(fespace)
+    parts = []
+    for k in (_GEO_AFFINE, _GEO_MULTILINEAR, _GEO_POINT):
+      sel = kind == k
+      count = int(sel.sum())
+      if count == 0:
+        continue
+      part = {'geo_mode': k}
+      if count < E:
+        part['elem_list'] = torch.nonzero(sel).reshape(-1).to(
+            torch.int32).contiguous()
+      if k == _GEO_POINT:
+        if count < E:
+          part['geo'] = _ops.helmholtz_setup(
+              fespace.invjacs[sel].contiguous(),
+              fespace.jacdets[sel].contiguous(), w)
+          part['geo_index'] = (torch.cumsum(sel, 0) - 1).to(
+              torch.int32).contiguous()
+        else:
+          part['geo'] = _ops.helmholtz_setup(fespace.invjacs, fespace.jacdets,
+                                             w)
+      else:
+        part['geo_elem'] = coef
+      parts.append(part)
+    mask = None
+    if dirichlet_mask is not None:
+      mask = (torch.as_tensor(dirichlet_mask, device=dev) == 0).to(
+          fespace.dtype)
+    host = {'dmat': _quadrature_dmat(fespace),
+            'weights': np.asarray(fespace.quadrature.weights),
+            'nodes': np.asarray(fespace.quadrature.nodes.node_values)}
+    return cls(fespace=fespace, parts=parts, host=host, mask=mask)
+
+  def apply_local(self, u_local, lambda0=0.0, lambda1=1.0):
+    """(E, n[, nc]) -> (E, n[, nc])."""
+    fes = self.fespace
+    mesh = fes.mesh
+    E, n = mesh.num_elements, mesh.num_nodes_per_element
+    scalar = u_local.dim() == 2
+    u3 = (u_local[..., None] if scalar else u_local).to(fes.dtype)
+    nc = u3.shape[-1]
+    q = fes.quadrature.num_points
+    uq = u3 if fes.is_collocated else fes._basis(u3, True, False)[0]
+    rq = _ops.helmholtz_local(uq.contiguous(), self.parts, self.host,
+                              mesh.ndim, q, lambda0, lambda1)
+    if fes.is_collocated:
+      r3 = rq
+    else:
+      i1, g1 = fes._matrices()
+      ones = fes._cache.get('ones_eq')
+      if ones is None:
+        ones = fes._cache['ones_eq'] = torch.ones(
+            (E, q ** mesh.ndim), dtype=fes.dtype, device=fes.device)
+      r3 = _ops.basis_eval_t(rq, None, i1, g1, None, ones, mesh.ndim,
+                             mesh.gridpoints_1d.num_points, q, nc, False)
+    return r3[..., 0] if scalar else r3
+
+  def apply(self, u, lambda0=0.0, lambda1=1.0):
+    """u (N,) or (N, nc) -> mask * scatter(local(gather(u)))."""
+    mesh = self.fespace.mesh
+    if u.shape[0] != mesh.num_nodes:
+      raise ValueError(f'expected {mesh.num_nodes} nodal values, got '
+                       f'{tuple(u.shape)}')
+    u = u.to(self.fespace.dtype)
+    if u.dim() == 1:
+      out = mesh.scatter(self.apply_local(mesh.gather(u), lambda0, lambda1))
+      return out if self.mask is None else out * self.mask
+    loc = self.apply_local(_ops.gather_rows(u.contiguous(), mesh.elements),
+                           lambda0, lambda1)
+    out = _ops.scatter_add(loc, mesh.elements, mesh.num_nodes, ncomp=u.shape[1])
+    return out if self.mask is None else out * self.mask[:, None]
+
+  def linear_operator(self, lambda0=0.0, lambda1=1.0):
+    return lambda u: self.apply(u, lambda0, lambda1)

@@ -578,6 +578,37 @@ def test_fused_helmholtz_padded_elements_and_errors():
 
 
 # ----------------------------------------------------------------------- CG
+@pytest.mark.parametrize('ndim,n,P,q,qt', [(2, 4, 4, 5, 'gl'), (2, 3, 2, 3, 'gl'),
+                                           (3, 2, 4, 6, 'gl'), (3, 2, 6, 8, 'gll'),
+                                           (3, 2, 3, 5, 'gl')])
+def test_two_grid_helmholtz_matches_oracle(ndim, n, P, q, qt):
+  """Quadrature != nodes (the Poisson example's Gauss rule, the convection
+  space's over-integration): interpolate -> fused kernel on the quadrature
+  grid -> transposed interpolation, vs the oracle's dense forms."""
+  from swirl_fem_amd.core import operators
+  rp = make_case(ndim, n, P, jitter=0.15, seed=21, scramble=True)
+  mesh, fes, ofes = spaces(rp, P, q, qt)
+  assert not fes.is_collocated and operators.supports_two_grid(fes) is None
+  bm = mesh.physical_masks['boundary']
+  bmask = bm.cpu().numpy()
+  rng = np.random.default_rng(22)
+  for geometry in ('auto', 'stored'):
+    op = fes.helmholtz_operator(bm, geometry)
+    assert isinstance(op, operators.TwoGridHelmholtzOperator)
+    if geometry == 'auto':
+      assert {p['geo_mode'] for p in op.parts} == {3}
+    for nc in (1, ndim):
+      u = rng.standard_normal((mesh.num_nodes, nc))
+      uu = u[:, 0] if nc == 1 else u
+      for l0, l1 in ((0.0, 1.0), (1.0, 0.0), (0.4, 1.3)):
+        ref = _helmholtz_ref(ofes, uu, l0, l1, bmask)
+        assert relerr(op.apply(dev(uu), l0, l1), ref) < 1e-10, (geometry, l0)
+  ul = rng.standard_normal(rp.elements.shape)
+  ref = 0.3 * ofes.mass_local(ul) + ofes.stiffness_local(ul)
+  assert relerr(fes.helmholtz_operator(None).apply_local(dev(ul), 0.3, 1.0),
+                ref) < 1e-10
+
+
 def test_cg_reference_known_answers():
   from swirl_fem_amd.linalg.cg import cg
   b = dev(np.arange(9.0).reshape(3, 3))
