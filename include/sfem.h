@@ -298,6 +298,14 @@ int sfem_stokes_setup(const void* invjac, const void* jacdet,
                       const void* weights_nd, void* kfac, int64_t num_elements,
                       int ndim, int Q, int dtype, sfem_stream_t stream);
 int sfem_stokes_div(const sfem_stokes_args* args, sfem_stream_t stream);
+/* Convection integrand on a collocated grid of P points per direction (the
+ * over-integration grid of StokesVelocity.C_local, navier_stokes.py:238-245,
+ * after interpolation to it):  u, out (E, P^ndim, ndim) element-local,
+ *   out[e,q,c] = w_q detJ_q sum_j u_j(x_q) d u_c/d x_j(x_q).
+ * `dmat`, `weights`, `nodes` are those of that grid; enc / penc / interp /
+ * p_in / p_out / scale are unused.                                           */
+int sfem_stokes_convect_local(const sfem_stokes_args* args,
+                              sfem_stream_t stream);
 int sfem_stokes_grad_t(const sfem_stokes_args* args, sfem_stream_t stream);
 
 /* ------------------------------------------------------------ CG kernels ---

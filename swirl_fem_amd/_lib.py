@@ -96,6 +96,7 @@ SIGNATURES = {
                           c_i32, c_ptr],
     'sfem_stokes_div': [c_ptr, c_ptr],
     'sfem_stokes_grad_t': [c_ptr, c_ptr],
+    'sfem_stokes_convect_local': [c_ptr, c_ptr],
     'sfem_abi_version': [],
 }
 

@@ -466,6 +466,33 @@ def stokes_grad_t(p, out, enc, penc, parts, host, ndim, P, zero_range):
   return out
 
 
+def stokes_convect_local(u_local, parts, host, ndim, P):
+  """(E, P^d, d) values on a collocated grid -> w detJ (u . grad) u there."""
+  u_local = u_local.contiguous()
+  dev = _dev(u_local)
+  E, n, d = u_local.shape
+  if d != ndim or n != P ** ndim:
+    raise ValueError(f'expected (E, {P ** ndim}, {ndim}) local values, got '
+                     f'{tuple(u_local.shape)}')
+  out = torch.empty_like(u_local)
+  host = {k: _host(v, u_local.dtype) for k, v in host.items()}
+  with torch.cuda.device(dev):
+    for part in parts:
+      lst = part.get('elem_list')
+      args = _lib.StokesArgs(
+          u=u_local.data_ptr(), out=out.data_ptr(),
+          kfac=_dptr(part.get('kfac')), geo_elem=_dptr(part.get('geo_elem')),
+          geo_index=_dptr(part.get('geo_index')), elem_list=_dptr(lst),
+          dmat=_hptr(host['dmat']), weights=_hptr(host['weights']),
+          nodes=_hptr(host['nodes']), num_elements=E,
+          num_listed=0 if lst is None else lst.numel(), ndim=ndim, P=P,
+          dtype=_dtype_code(u_local), geo_mode=part['geo_mode'])
+      _lib.check(_lib.load().sfem_stokes_convect_local(ctypes.byref(args),
+                                                       _stream(dev)),
+                 'sfem_stokes_convect_local')
+  return out
+
+
 from swirl_fem_amd.core.layout import is_component_major  # noqa: E402
 
 

@@ -563,3 +563,93 @@ class TwoGridHelmholtzOperator:
 
   def linear_operator(self, lambda0=0.0, lambda1=1.0):
     return lambda u: self.apply(u, lambda0, lambda1)
+
+
+# ---------------------------------------------------------------------------
+# Over-integrated convection
+# ---------------------------------------------------------------------------
+def _grid_geometry_parts(fespace, point_setup, geometry='auto'):
+  """One launch description per geometry kind for kernels that work on the
+  quadrature grid of `fespace` (`point_setup(invjacs, jacdets, w)` builds the
+  stored per-point data of curved elements)."""
+  from swirl_fem_amd.core.interpolation import NodeType
+  mesh = fespace.mesh
+  E, dev = mesh.num_elements, fespace.device
+  w = torch.as_tensor(fespace.quadrature.weights_nd(mesh.ndim),
+                      dtype=fespace.dtype, device=dev)
+  corners = mesh.gridpoints_1d.node_type in (
+      NodeType.GAUSS_LOBATTO_LEGENDRE, NodeType.NEWTON_COTES)
+  if geometry == 'stored' or not corners:
+    kind = torch.zeros(E, dtype=torch.int32, device=dev)
+    coef = None
+  else:
+    kind, coef = classify_geometry(fespace)
+  parts = []
+  for k in (_GEO_AFFINE, _GEO_MULTILINEAR, _GEO_POINT):
+    sel = kind == k
+    count = int(sel.sum())
+    if count == 0:
+      continue
+    part = {'geo_mode': k}
+    if count < E:
+      part['elem_list'] = torch.nonzero(sel).reshape(-1).to(
+          torch.int32).contiguous()
+    if k == _GEO_POINT:
+      if count < E:
+        part['kfac'] = point_setup(fespace.invjacs[sel].contiguous(),
+                                   fespace.jacdets[sel].contiguous(), w)
+        part['geo_index'] = (torch.cumsum(sel, 0) - 1).to(
+            torch.int32).contiguous()
+      else:
+        part['kfac'] = point_setup(fespace.invjacs, fespace.jacdets, w)
+    else:
+      part['geo_elem'] = coef
+    parts.append(part)
+  return parts
+
+
+@dataclasses.dataclass(eq=False)
+class ConvectionOperator:
+  """`C_local(u)_{i,c} = int phi_i u_j d_j u_c` on the over-integration space
+  (navier_stokes.py:238-245) as: interpolate the nodal velocity to the
+  quadrature grid (`sfem_basis_eval`), one fused kernel there
+  (`sfem_stokes_convect_local`: collocated derivative lines, cofactor
+  geometry, contravariant velocity, product), transposed interpolation
+  (`sfem_basis_eval_t`).  Nothing of size (E, Q, d, d) is ever stored."""
+  fespace: object
+  parts: list
+  host: dict
+
+  @classmethod
+  def create(cls, fespace, geometry='auto') -> 'ConvectionOperator':
+    why = supports_two_grid(fespace)
+    q = fespace.quadrature.num_points
+    if why is None and q < 4:
+      why = f'q={q} < 4'
+    if why is not None:
+      raise NotImplementedError(f'fused convection unavailable: {why}')
+    parts = _grid_geometry_parts(fespace, _ops.stokes_setup, geometry)
+    host = {'dmat': _quadrature_dmat(fespace),
+            'weights': np.asarray(fespace.quadrature.weights),
+            'nodes': np.asarray(fespace.quadrature.nodes.node_values)}
+    return cls(fespace=fespace, parts=parts, host=host)
+
+  def apply_local(self, u_local):
+    """(E, n, d) nodal velocity -> (E, n, d) local convection covector."""
+    fes = self.fespace
+    mesh = fes.mesh
+    q = fes.quadrature.num_points
+    u3 = u_local.to(fes.dtype)
+    uq = u3 if fes.is_collocated else fes._basis(u3, True, False)[0]
+    cq = _ops.stokes_convect_local(uq, self.parts, self.host, mesh.ndim, q)
+    if fes.is_collocated:
+      return cq
+    i1, g1 = fes._matrices()
+    ones = fes._cache.get('ones_eq')
+    if ones is None:
+      ones = fes._cache['ones_eq'] = torch.ones(
+          (mesh.num_elements, q ** mesh.ndim), dtype=fes.dtype,
+          device=fes.device)
+    return _ops.basis_eval_t(cq, None, i1, g1, None, ones, mesh.ndim,
+                             mesh.gridpoints_1d.num_points, q, mesh.ndim,
+                             False)

@@ -492,9 +492,103 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
   }
 }
 
+// Convection on a collocated grid (the over-integration grid of
+// StokesVelocity.C_local, navier_stokes.py:238-245, reached by interpolation):
+//   out[e, q, c] = w_q detJ_q  sum_j u_j(x_q) d u_c / d x_j (x_q)
+//                = w_q sum_a ( sum_j K[a][j] u_j ) d u_c / d xi_a
+// Element-local in and out, (E, n, DIM) row-major; the transposed
+// interpolation back to the nodes and the scatter follow in separate kernels.
+template <typename T, int P, int DIM, int GM>
+__global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
+                                  (HelmholtzTile<T, P, DIM>::MINW))
+stokes_convect_kernel(StokesParams<T> prm, DMat<T, P> dm) {
+  using Tile = HelmholtzTile<T, P, DIM>;
+  constexpr int TPE = Tile::TPE, SA = Tile::SA, SB = Tile::SB;
+  constexpr int EPB = Tile::EPB, W = Tile::ELEM_WORDS;
+  constexpr int N = DIM == 3 ? P * P * P : P * P;
+  __shared__ T lds[2 * EPB * W];
+  const int tid = threadIdx.x;
+  const int el = tid / TPE;
+  const int t = tid - el * TPE;
+  const int i = DIM == 3 ? t / P : 0;
+  const int j = DIM == 3 ? t - i * P : t;
+  const bool lane_ok = el < EPB;
+  const int64_t work = (int64_t)blockIdx.x * EPB + (lane_ok ? el : 0);
+  const bool active = lane_ok && work < prm.num_elements;
+  const int64_t e =
+      prm.elem_list ? (active ? (int64_t)prm.elem_list[work] : 0) : work;
+  T* s0 = lds + (lane_ok ? el : 0) * 2 * W;
+  T* s1 = s0 + W;
+  (void)s1;
+  ElemCof<T, P, DIM, GM> geom;
+  geom.init(prm, dm, e, active, i, j, t);
+  const T* ue = prm.u + e * N * DIM;
+  T* oe = prm.out + e * N * DIM;
+
+  T uall[DIM][P];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c)
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+      uall[c][a] = active ? ue[(int64_t)(t + a * TPE) * DIM + c] : T(0);
+
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) {
+    cof_fence(geom);
+    T d0[P];
+    line_apply<T, P, false>(dm, uall[c], d0);
+    if (lane_ok) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        s0[a * SA + i * SB + j] = uall[c][a];
+        if (DIM == 3) s1[a * SA + i * SB + j] = uall[c][a];
+      }
+    }
+    __syncthreads();
+    if (lane_ok) {  // last axis
+      T* line = (DIM == 3 ? s1 + i * SA + j * SB : s0 + j * SA);
+      T x[P], y[P];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = line[m];
+      line_apply<T, P, false>(dm, x, y);
+#pragma unroll
+      for (int m = 0; m < P; ++m) line[m] = y[m];
+    }
+    if (DIM == 3 && lane_ok) {  // middle axis
+      T* line = s0 + i * SA + j;
+      T x[P], y[P];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = line[m * SB];
+      line_apply<T, P, false>(dm, x, y);
+#pragma unroll
+      for (int m = 0; m < P; ++m) line[m * SB] = y[m];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        const int o = a * SA + i * SB + j;
+        T K[DIM * DIM];
+        geom.cof(dm, a, K);
+        T v = T(0);
+#pragma unroll
+        for (int ax = 0; ax < DIM; ++ax) {
+          T U = T(0);                 // contravariant velocity along xi_ax
+#pragma unroll
+          for (int jj = 0; jj < DIM; ++jj) U += K[ax * DIM + jj] * uall[jj][a];
+          const T g = ax == 0 ? d0[a] : (ax == 1 ? s0[o] : s1[o]);
+          v += U * g;
+        }
+        oe[(int64_t)(t + a * TPE) * DIM + c] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T, int P, int DIM>
-int launch_stokes(const StokesParams<T>& prm, bool grad_t,
-                  hipStream_t stream) {
+int launch_stokes(const StokesParams<T>& prm, int mode, hipStream_t stream) {
+  const bool grad_t = mode == 1;
   constexpr int PP = P - 2;
   using Tile = HelmholtzTile<T, P, DIM>;
   const int64_t groups = (prm.num_elements + Tile::EPB - 1) / Tile::EPB;
@@ -505,10 +599,14 @@ int launch_stokes(const StokesParams<T>& prm, bool grad_t,
   const DMat<T, P> dm =
       make_dmat<T, P>(prm.dmat_host, prm.weights_host, prm.nodes_host);
   IMat<T, P, PP> im;
-  for (int q = 0; q < P * PP; ++q) im.m[q] = prm.interp_host[q];
+  for (int q = 0; q < P * PP; ++q)
+    im.m[q] = prm.interp_host ? prm.interp_host[q] : T(0);
   const dim3 grid((unsigned)groups), block(Tile::BLOCK);
 #define SFEM_LAUNCH_STOKES(GMV)                                               \
-  if (grad_t)                                                                 \
+  if (mode == 2)                                                              \
+    hipLaunchKernelGGL((stokes_convect_kernel<T, P, DIM, GMV>), grid, block,  \
+                       0, stream, prm, dm);                                   \
+  else if (grad_t)                                                            \
     hipLaunchKernelGGL((stokes_grad_t_kernel<T, P, PP, DIM, GMV>), grid,      \
                        block, 0, stream, prm, dm, im);                        \
   else                                                                        \
@@ -526,16 +624,16 @@ int launch_stokes(const StokesParams<T>& prm, bool grad_t,
 
 // Defined once per (dtype, ndim) translation unit.
 template <typename T, int DIM>
-int dispatch_stokes(const StokesParams<T>& prm, int P, bool grad_t,
+int dispatch_stokes(const StokesParams<T>& prm, int P, int mode,
                     hipStream_t stream);
 
 #define SFEM_STOKES_CASE(PP_) \
-  case PP_: return launch_stokes<T, PP_, DIM>(prm, grad_t, stream);
+  case PP_: return launch_stokes<T, PP_, DIM>(prm, mode, stream);
 
 #define SFEM_DEFINE_STOKES_DISPATCH(TYPE, DIMV)                              \
   template <>                                                                \
   int dispatch_stokes<TYPE, DIMV>(const StokesParams<TYPE>& prm, int P,      \
-                                  bool grad_t, hipStream_t stream) {         \
+                                  int mode, hipStream_t stream) {            \
     using T = TYPE;                                                          \
     constexpr int DIM = DIMV;                                                \
     switch (P) {                                                             \

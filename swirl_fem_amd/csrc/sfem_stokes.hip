@@ -26,7 +26,7 @@ stokes_setup_kernel(const T* __restrict__ invjac, const T* __restrict__ jacdet,
 }
 
 template <typename T>
-static int run_stokes(const sfem_stokes_args* a, bool grad_t,
+static int run_stokes(const sfem_stokes_args* a, int mode,
                       hipStream_t stream) {
   StokesParams<T> prm{};
   prm.u = (const T*)a->u; prm.out = (T*)a->out;
@@ -48,8 +48,8 @@ static int run_stokes(const sfem_stokes_args* a, bool grad_t,
     prm.scale_node_stride = prm.node_stride;
     prm.scale_comp_stride = prm.comp_stride;
   }
-  if (a->ndim == 3) return dispatch_stokes<T, 3>(prm, a->P, grad_t, stream);
-  return dispatch_stokes<T, 2>(prm, a->P, grad_t, stream);
+  if (a->ndim == 3) return dispatch_stokes<T, 3>(prm, a->P, mode, stream);
+  return dispatch_stokes<T, 2>(prm, a->P, mode, stream);
 }
 
 static int check_stokes(const char* who, const sfem_stokes_args* a) {
@@ -62,7 +62,7 @@ static int check_stokes(const char* who, const sfem_stokes_args* a) {
   SFEM_REQUIRE(a->dtype == SFEM_F32 || a->dtype == SFEM_F64,
                "%s: unknown dtype %d", who, a->dtype);
   if (a->num_elements == 0) return SFEM_OK;
-  SFEM_REQUIRE(a->enc && a->dmat && a->interp, "%s: null pointer", who);
+  SFEM_REQUIRE(a->dmat, "%s: null pointer", who);
   if (a->geo_mode == SFEM_GEO_POINT) {
     SFEM_REQUIRE(a->kfac, "%s: per-point geometry needs `kfac`", who);
   } else if (a->geo_mode == SFEM_GEO_AFFINE ||
@@ -113,19 +113,32 @@ int sfem_stokes_setup(const void* invjac, const void* jacdet,
   return SFEM_OK;
 }
 
-int sfem_stokes_div(const sfem_stokes_args* a, sfem_stream_t stream) {
-  int rc = check_stokes("sfem_stokes_div", a);
+int sfem_stokes_convect_local(const sfem_stokes_args* a, sfem_stream_t stream) {
+  int rc = check_stokes("sfem_stokes_convect_local", a);
   if (rc) return rc;
   const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
   if (work == 0) return SFEM_OK;
+  SFEM_REQUIRE(a->u && a->out, "sfem_stokes_convect_local: null pointer");
+  if (a->dtype == SFEM_F64) return run_stokes<double>(a, 2, as_stream(stream));
+  return run_stokes<float>(a, 2, as_stream(stream));
+}
+
+int sfem_stokes_div(const sfem_stokes_args* a, sfem_stream_t stream) {
+  int rc = check_stokes("sfem_stokes_div", a);
+  if (rc) return rc;
+  SFEM_REQUIRE(a->enc && a->interp, "sfem_stokes_div: null pointer");
+  const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
+  if (work == 0) return SFEM_OK;
   SFEM_REQUIRE(a->u && a->p_out, "sfem_stokes_div: null pointer");
-  if (a->dtype == SFEM_F64) return run_stokes<double>(a, false, as_stream(stream));
-  return run_stokes<float>(a, false, as_stream(stream));
+  if (a->dtype == SFEM_F64) return run_stokes<double>(a, 0, as_stream(stream));
+  return run_stokes<float>(a, 0, as_stream(stream));
 }
 
 int sfem_stokes_grad_t(const sfem_stokes_args* a, sfem_stream_t stream) {
   int rc = check_stokes("sfem_stokes_grad_t", a);
   if (rc) return rc;
+  SFEM_REQUIRE(a->num_elements == 0 || (a->enc && a->interp),
+               "sfem_stokes_grad_t: null pointer");
   SFEM_REQUIRE(a->zero_begin >= 0 && a->zero_end >= a->zero_begin &&
                    a->zero_end <= a->num_nodes,
                "sfem_stokes_grad_t: bad zero range");
@@ -150,8 +163,8 @@ int sfem_stokes_grad_t(const sfem_stokes_args* a, sfem_stream_t stream) {
     }
   }
   if (work == 0) return SFEM_OK;
-  if (a->dtype == SFEM_F64) return run_stokes<double>(a, true, as_stream(stream));
-  return run_stokes<float>(a, true, as_stream(stream));
+  if (a->dtype == SFEM_F64) return run_stokes<double>(a, 1, as_stream(stream));
+  return run_stokes<float>(a, 1, as_stream(stream));
 }
 
 }  // extern "C"

@@ -250,6 +250,16 @@ class StokesVelocity:
 
   def C_local(self, u_local):
     """Apply the local convection operator."""
+    cache = self.overint_space._cache
+    if 'convection' not in cache:
+      try:
+        cache['convection'] = operators.ConvectionOperator.create(
+            self.overint_space)
+      except NotImplementedError:      # fall back to the generic form below
+        cache['convection'] = None
+    if cache['convection'] is not None:
+      return cache['convection'].apply_local(u_local)
+
     def c(u, w, v):
       return lambda x: torch.einsum('i,ij,j->', u(x), grad(w)(x), v(x))
 

@@ -232,3 +232,29 @@ def test_stokes_properties_at_scale():
   a, b = float(torch.dot(Ep, q)), float(torch.dot(p, Eq))
   assert abs(a - b) < 1e-9 * abs(a)
   assert float(torch.dot(Ep, p)) > 0
+
+
+@pytest.mark.parametrize('ndim,n,P,extra', [(2, 4, 6, 2), (2, 3, 4, 3),
+                                            (3, 2, 4, 2), (3, 2, 8, 2),
+                                            (3, 2, 5, 0)])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_fused_convection_matches_oracle(ndim, n, P, extra, dtype):
+  """C_local on the over-integration space (navier_stokes.py:183-188,
+  :238-245): interpolate -> fused kernel on the quadrature grid -> transposed
+  interpolation, vs the oracle's dense evaluation, incl. reflected elements."""
+  tol = 1e-10 if dtype == torch.float64 else 5e-5
+  rng = np.random.default_rng(31)
+  pm = unit_cube_mesh(n, ndim=ndim)
+  pm = pm.replace(node_coords=pm.node_coords + 0.15 / n * rng.uniform(
+      -1, 1, pm.node_coords.shape))
+  pm = reorient(pm, rng)
+  rv = refine_premesh(pm, Nodes1D.create(P, GLL))
+  q = P + extra
+  quad = Quadrature1D.create_from_nodes_1d(Nodes1D.create(q, GLL))
+  fes = FiniteElementSpace.create(rv.finalize(device=DEV, dtype=dtype), quad)
+  ofes = O.FESpace(rv.node_coords, rv.elements, (P, 'gll'), (q, 'gll'))
+  ul = rng.standard_normal(rv.elements.shape + (ndim,))
+  ref = ofes.convection_local(ul, ul)
+  for geometry in ('auto', 'stored'):
+    op = operators.ConvectionOperator.create(fes, geometry)
+    assert relerr(op.apply_local(dev(ul, dtype)), ref) < tol, geometry
