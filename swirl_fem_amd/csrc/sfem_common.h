@@ -42,11 +42,22 @@ inline hipStream_t as_stream(sfem_stream_t s) {
     }                                                                    \
   } while (0)
 
-// Streaming kernels: enough workgroups to fill 256 CUs several times over,
-// grid-stride the rest.
+// Streaming kernels: grid-stride over at most 128 workgroups per CU.  Measured
+// on MI355X (90 M doubles): y = a x + b y reaches 4.7 TB/s with 16 workgroups
+// per CU, 5.3 with 64, 5.5 with 128 and no more beyond.
 inline unsigned stream_grid(int64_t work_items, int block) {
   int64_t blocks = (work_items + block - 1) / block;
-  const int64_t cap = 256 * 16;
+  const int64_t cap = 256 * 128;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return static_cast<unsigned>(blocks);
+}
+
+// Kernels that end in one atomic per workgroup (dot products, the fused r.r):
+// 64 workgroups per CU; more only lengthens the atomic tail on one address.
+inline unsigned reduce_grid(int64_t work_items, int block) {
+  int64_t blocks = (work_items + block - 1) / block;
+  const int64_t cap = 256 * 64;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return static_cast<unsigned>(blocks);

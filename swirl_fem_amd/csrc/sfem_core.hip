@@ -629,7 +629,7 @@ int sfem_dot(const void* a, const void* b, int64_t count, double* result,
   if (count == 0) return SFEM_OK;
   SFEM_REQUIRE(a && b, "sfem_dot: null pointer");
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
-      dot_kernel<T>, dim3(stream_grid(count, 512 * 4)), dim3(512), 0,
+      dot_kernel<T>, dim3(reduce_grid(count, 512 * 4)), dim3(512), 0,
       as_stream(stream), (const T*)a, (const T*)b, count, result));
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
@@ -641,7 +641,7 @@ int sfem_dot_accumulate(const void* a, const void* b, int64_t count,
   if (count == 0) return SFEM_OK;
   SFEM_REQUIRE(a && b, "sfem_dot_accumulate: null pointer");
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
-      dot_kernel<T>, dim3(stream_grid(count, 512 * 4)), dim3(512), 0,
+      dot_kernel<T>, dim3(reduce_grid(count, 512 * 4)), dim3(512), 0,
       as_stream(stream), (const T*)a, (const T*)b, count, result));
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
@@ -653,7 +653,7 @@ int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,
   SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_xr: bad arguments");
   if (count == 0) return SFEM_OK;
   SFEM_REQUIRE(x && r && p && ap, "sfem_cg_update_xr: null pointer");
-  const unsigned grid = stream_grid(count, 512 * 2);
+  const unsigned grid = reduce_grid(count, 512 * 2);
   DISPATCH_DTYPE(dtype, {
     if (fuse_rr)
       hipLaunchKernelGGL((cg_update_xr_kernel<T, true>), dim3(grid), dim3(512),
@@ -686,7 +686,7 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
   if (count == 0) return SFEM_OK;
   SFEM_REQUIRE(r && ap, "sfem_cg_update_r: null pointer");
   DISPATCH_DTYPE(dtype, {
-    const int grid = stream_grid(count, 512 * 2);
+    const int grid = reduce_grid(count, 512 * 2);
     if (fuse_rr)
       hipLaunchKernelGGL((cg_update_r_kernel<T, true>), dim3(grid), dim3(512),
                          0, as_stream(stream), (T*)r, (const T*)ap, count,

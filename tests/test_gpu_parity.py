@@ -569,10 +569,15 @@ def test_fused_helmholtz_padded_elements_and_errors():
   got = fes.helmholtz_operator(None).apply(dev(u), 0.2, 1.0)
   assert torch.isfinite(got).all()
   assert relerr(got, _helmholtz_ref(ofes, u, 0.2, 1.0, None)) < 1e-10
-  # non-collocated spaces have no fused kernel
+  # quadrature != nodes: the two-grid operator, also with padded elements
   fes2 = FiniteElementSpace.create(mesh, Quadrature1D.create(5, NT['gl']))
+  ofes2 = O.FESpace(rp.node_coords, rp.elements, (4, 'gll'), (5, 'gl'))
+  got2 = fes2.helmholtz_operator(None).apply(dev(u), 0.2, 1.0)
+  assert relerr(got2, _helmholtz_ref(ofes2, u, 0.2, 1.0, None)) < 1e-10
+  # more quadrature points than the kernels are compiled for
+  fes3 = FiniteElementSpace.create(mesh, Quadrature1D.create(13, NT['gl']))
   with pytest.raises(NotImplementedError):
-    fes2.helmholtz_operator(None)
+    fes3.helmholtz_operator(None)
   with pytest.raises(ValueError):
     fes.helmholtz_operator(None).apply(dev(u[:-1]))
 
