@@ -113,7 +113,7 @@ def test_partitioned_cg_on_one_gpu(grid, n, P, dtype_name):
     assert abs(res[r]['its'] - res[r]['its_ref']) <= 5
 
 
-def _gmsh_worker(rank, world, port, P, results):
+def _gmsh_worker(rank, world, port, P, source, results):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -129,25 +129,35 @@ def _gmsh_worker(rank, world, port, P, results):
     path = os.path.join(os.path.dirname(__file__), 'golden', 'msh', 'cube.msh')
     nodes = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
     quad = Quadrature1D.create_from_nodes_1d(nodes)
-    pm = mesh_reader.read(path, ndim=3)
-    rp = refine_premesh(mesh_partitioner.partition(pm, world), nodes)
+    if source == 'gmsh':
+      pm = mesh_reader.read(path, ndim=3)
+      rp = refine_premesh(mesh_partitioner.partition(pm, world), nodes)
+    else:
+      # periodic in the partitioned direction: the two ranks meet twice, at
+      # the cut and through the wrap-around (config 4's situation)
+      from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+      pm = unit_cube_mesh(4, ndim=3, periodic_dims=(0,))
+      rp = refine_premesh(pm.replace(partitions=np.repeat(
+          np.arange(world), pm.num_elements // world).astype(np.int32)), nodes)
     mesh = rp.finalize('parts', rank=rank, device=dev)
     arrays = rp.finalize_all('parts')
     gids = arrays['global_node_ids'][rank]                  # -1 = padding
     real = torch.as_tensor(gids >= 0, device=dev)
     x = mesh.node_coords
-    dirichlet = ((x[:, 0] < 1e-9) | (x[:, 0] > 1 - 1e-9)) | ~real
+    ax = 0 if source == 'gmsh' else 1          # Dirichlet planes
+    dirichlet = ((x[:, ax] < 1e-9) | (x[:, ax] > 1 - 1e-9)) | ~real
     fes = FiniteElementSpace.create(mesh, quad)
     op = fes.helmholtz_operator(dirichlet)
     A = op.linear_operator(0.5, 1.0)
     # the same problem on the whole mesh, one rank
     gmesh = refine_premesh(pm, nodes).finalize(device=dev)
     gx = gmesh.node_coords
-    gdir = (gx[:, 0] < 1e-9) | (gx[:, 0] > 1 - 1e-9)
+    gdir = (gx[:, ax] < 1e-9) | (gx[:, ax] > 1 - 1e-9)
     gop = FiniteElementSpace.create(gmesh, quad).helmholtz_operator(gdir)
-    f = torch.sin(3 * gx[:, 0]) * torch.cos(2 * gx[:, 1]) + gx[:, 2]
-    xg, _ = cg(gop.linear_operator(0.5, 1.0), gop.apply(f * ~gdir, 1.0, 0.0),
-               tol=1e-12, maxiter=3000)
+    f = torch.sin(2 * np.pi * gx[:, 0]) * torch.cos(2 * gx[:, 1]) + gx[:, 2]
+    # reference convention: unassembled operator, M = exchange (periodic)
+    xg, _ = cg(lambda u: gop.apply(u, 0.5, 1.0), gop.apply(f * ~gdir, 1.0, 0.0),
+               tol=1e-12, maxiter=3000, M=gmesh.exchange)
     # partitioned: unassembled local load vector of the same forcing
     ids = torch.as_tensor(np.where(gids >= 0, gids, 0), device=dev)
     f_loc = f[ids] * ~dirichlet
@@ -162,8 +172,9 @@ def _gmsh_worker(rank, world, port, P, results):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,P', [(2, 4), (3, 3)])
-def test_gmsh_partitioned_solve_matches_single_rank(world, P):
+@pytest.mark.parametrize('world,P,source', [(2, 4, 'gmsh'), (3, 3, 'gmsh'),
+                                            (2, 4, 'periodic_x')])
+def test_gmsh_partitioned_solve_matches_single_rank(world, P, source):
   """Gmsh file -> native reader -> coordinate-bisection partitioner -> refiner
   -> reference-style (P, S) exchange table -> neighbour plan -> partitioned CG
   on the GPU; equals the one-rank solve of the same mesh (uneven partitions
@@ -171,8 +182,8 @@ def test_gmsh_partitioned_solve_matches_single_rank(world, P):
   port = _free_port()
   with mp.Manager() as mgr:
     results = mgr.dict()
-    mp.spawn(_gmsh_worker, args=(world, port, P, results), nprocs=world,
-             join=True)
+    mp.spawn(_gmsh_worker, args=(world, port, P, source, results),
+             nprocs=world, join=True)
     res = dict(results)
   assert sorted(res) == list(range(world))
   assert sum(r['elems'] for r in res.values()) == 64
