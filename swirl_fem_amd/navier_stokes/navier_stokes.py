@@ -80,9 +80,9 @@ def _pressure_project_out_nullspace(sem, p):
   key = ('pressure_mass_ones', p.dtype)
   if key not in sem._cache:
     b1 = sem.pressure.B(torch.ones_like(p))
-    sem._cache[key] = (b1, torch.sum(b1))
+    sem._cache[key] = (b1, sem._global_sum(torch.sum(b1).reshape(1)))
   b1, total = sem._cache[key]
-  return w - torch.vdot(b1, w) / total
+  return w - sem._global_sum(torch.vdot(b1, w).reshape(1)) / total
 
 
 @enum.unique
@@ -114,11 +114,12 @@ class StokesPressure:
 
   @classmethod
   def create(cls, premesh: Premesh, quadrature: Quadrature1D, order: int,
-             device=None, dtype=None) -> 'StokesPressure':
+             device=None, dtype=None, axis_name=None,
+             rank=None) -> 'StokesPressure':
     gridpoints_1d = Nodes1D.create(num_points=order - 1,
                                    node_type=NodeType.GAUSS_LEGENDRE)
     pmesh = refine_premesh(premesh, gridpoints_1d=gridpoints_1d).finalize(
-        device=device, dtype=dtype)
+        axis_name, rank=rank, device=device, dtype=dtype)
     return cls(pspace=FiniteElementSpace.create(mesh=pmesh,
                                                 quadrature=quadrature))
 
@@ -156,14 +157,19 @@ class StokesVelocity:
   @classmethod
   def create(cls, premesh: Premesh, order: int, boundary_conditions,
              num_convection_overint_nodes: int = 2, device=None,
-             dtype=None) -> 'StokesVelocity':
+             dtype=None, axis_name=None, rank=None) -> 'StokesVelocity':
     gridpoints_1d = Nodes1D.create(
         num_points=order + 1, node_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
     vmesh = refine_premesh(premesh, gridpoints_1d=gridpoints_1d).finalize(
-        device=device, dtype=dtype)
+        axis_name, rank=rank, device=device, dtype=dtype)
     vspace = FiniteElementSpace.create(
         mesh=vmesh, quadrature=Quadrature1D.create_from_nodes_1d(gridpoints_1d))
-    interior_mask = dirichlet_bc(vmesh, boundary_conditions)[:, None]
+    interior_mask = dirichlet_bc(vmesh, boundary_conditions)
+    if vmesh.axis_name is not None and vmesh.node_indices is not None:
+      # padding nodes of an uneven partition carry no equation
+      interior_mask = interior_mask * (vmesh.node_indices >= 0).to(
+          interior_mask.dtype)
+    interior_mask = interior_mask[:, None]
     overint_gridpoints_1d = Nodes1D.create(
         num_points=gridpoints_1d.num_points + num_convection_overint_nodes,
         node_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
@@ -172,6 +178,9 @@ class StokesVelocity:
         quadrature=Quadrature1D.create_from_nodes_1d(overint_gridpoints_1d))
     diag_qqt = vmesh.scatter(torch.ones(
         tuple(vmesh.elements.shape), dtype=vmesh.dtype, device=vmesh.device))
+    if vmesh.axis_name is not None:
+      # multiplicity over all partitions; padding nodes (count 0) -> 1
+      diag_qqt = vmesh.exchange(diag_qqt).clamp(min=1.0)
     return cls(vspace=vspace, overint_space=overint_space, diag_qqt=diag_qqt,
                interior_mask=interior_mask,
                num_convection_overint_nodes=num_convection_overint_nodes)
@@ -280,16 +289,23 @@ class StokesSEM:
   @classmethod
   def create(cls, premesh: Premesh, boundary_conditions, order: int,
              num_convection_overint_nodes: int = 2, *, device=None,
-             dtype=None) -> 'StokesSEM':
+             dtype=None, axis_name=None, rank=None) -> 'StokesSEM':
+    """`axis_name` / `rank`: build this rank's partition of a partitioned
+    premesh (one process per GPU; the reference has no partitioned
+    Navier-Stokes path).  Fields are then consistent across partitions, right
+    hand sides unassembled, `M = exchange` assembles inside the solves and the
+    inner products are all-reduced."""
     if premesh.order != 1:
       raise ValueError(f'Expected mesh order 1; got {premesh.order}.')
     quadrature = Quadrature1D.create(
         num_points=order + 1, quadrature_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
     pressure = StokesPressure.create(premesh, quadrature, order, device=device,
-                                     dtype=dtype)
+                                     dtype=dtype, axis_name=axis_name,
+                                     rank=rank)
     velocity = StokesVelocity.create(premesh, order, boundary_conditions,
                                      num_convection_overint_nodes,
-                                     device=device, dtype=dtype)
+                                     device=device, dtype=dtype,
+                                     axis_name=axis_name, rank=rank)
     ones = torch.ones(velocity.local_shape, dtype=velocity.mesh.dtype,
                       device=velocity.mesh.device)
     velocity_mass_diag = velocity.scatter(velocity.B_local(ones))
@@ -299,6 +315,21 @@ class StokesSEM:
   def replace(self, **kw):
     kw.setdefault('_cache', {})
     return dataclasses.replace(self, **kw)
+
+  # ------------------------------------------------------------- partitions
+  @property
+  def is_partitioned(self) -> bool:
+    return self.velocity.mesh.axis_name is not None
+
+  def _global_sum(self, t):
+    """Sum of a device tensor over the partitions (identity on one rank)."""
+    if self.is_partitioned:
+      from swirl_fem_amd.distributed import comm
+      comm.all_reduce_sum_(t)
+    return t
+
+  def _reduce_fn(self):
+    return self._global_sum if self.is_partitioned else None
 
   # ----------------------------------------------------------------- operators
   def B(self, u):
@@ -449,7 +480,7 @@ class StokesSEM:
     graph = (self.velocity.mesh.axis_name is None and
              os.environ.get('SFEM_GRAPHS', '1') != '0')
     u_star, info = cg(H_, f, M=self.velocity.exchange, tol=tol, atol=atol,
-                      graph=graph)
+                      graph=graph, reduce_fn=self._reduce_fn())
     if u_boundary is not None:
       u_star = u_star + u_boundary
     aux = {'u_star_info': info}
@@ -458,7 +489,7 @@ class StokesSEM:
 
     dp, info = cg(partial(self.E, dt=dt, time_order=time_order),
                   -self.D(u_star), M=pressure_preconditioner, tol=tol,
-                  atol=atol, graph=graph)
+                  atol=atol, graph=graph, reduce_fn=self._reduce_fn())
     aux['dp_info'] = info
 
     u = u_star + self.Q(self.Dt(dp), dt=dt, time_order=time_order)
@@ -478,8 +509,9 @@ class StokesSEM:
     u_local = self.velocity.gather(u)
     filtered_local = basis.interp(high_interp, basis.interp(low_interp,
                                                             u_local))
-    filtered = (1 / self.velocity.diag_qqt[:, None]) * self.velocity.scatter(
-        filtered_local)
+    filtered = (1 / self.velocity.diag_qqt[:, None]) * (
+        self.velocity.exchange(self.velocity.scatter(filtered_local))
+        if self.is_partitioned else self.velocity.scatter(filtered_local))
     return (1 - alpha) * u + alpha * filtered
 
   def vorticity(self, u):

@@ -191,3 +191,78 @@ def test_gmsh_partitioned_solve_matches_single_rank(world, P, source):
     assert res[r]['shared'] > 0
     assert res[r]['err'] < 1e-9, res[r]
     assert res[r]['its'] == res[0]['its']
+
+
+def _ns_worker(rank, world, port, order, results):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+    from swirl_fem_amd.core.interpolation import Nodes1D, NodeType
+    from swirl_fem_amd.core.mesh_refiner import refine_premesh
+    from swirl_fem_amd.examples.navier_stokes_driver import (
+        _histories, navier_stokes_step)
+    from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
+    dev = torch.device('cuda', 0)
+    pm = unit_cube_mesh(4, ndim=3, periodic_dims=(0,))
+    parts = np.repeat(np.arange(world), pm.num_elements // world).astype(
+        np.int32)
+    bcs = {'boundary': (BCType.DIRICHLET, 0.0)}
+
+    def run(sem):
+      x = sem.velocity.mesh.node_coords
+      wall = torch.sin(np.pi * x[:, 1]) * torch.sin(np.pi * x[:, 2])
+      u0 = torch.stack([torch.sin(2 * np.pi * x[:, 0]) * wall,
+                        torch.cos(2 * np.pi * x[:, 0]) * wall * x[:, 1],
+                        0.5 * wall], dim=-1)
+      p0 = torch.zeros(sem.pressure.pspace.mesh.num_nodes, dtype=x.dtype,
+                       device=dev)
+      us, ps, Cus = _histories(sem, u0, p0, 2)
+      for _ in range(2):
+        u, p, Cu, aux = navier_stokes_step(
+            sem, us, ps, Cus, reynolds=50.0, dt=1e-2, time_order=2,
+            tol=1e-11, atol=0.0)
+        us, ps, Cus = us[1:] + (u,), ps[1:] + (p,), Cus[1:] + (Cu,)
+      return u, p, aux
+
+    sem_p = StokesSEM.create(pm.replace(partitions=parts), bcs, order,
+                             device=dev, axis_name='parts', rank=rank)
+    assert sem_p.is_partitioned and sem_p._divgrad() is not None
+    u_p, p_p, aux = run(sem_p)
+    sem_g = StokesSEM.create(pm, bcs, order, device=dev)
+    u_g, p_g, _ = run(sem_g)
+    gl = NodeType.GAUSS_LEGENDRE
+    gll = NodeType.GAUSS_LOBATTO_LEGENDRE
+    pp = pm.replace(partitions=parts)
+    vid = refine_premesh(pp, Nodes1D.create(order + 1, gll)).finalize_all(
+        'parts')['global_node_ids'][rank]
+    pid = refine_premesh(pp, Nodes1D.create(order - 1, gl)).finalize_all(
+        'parts')['global_node_ids'][rank]
+    vt = torch.as_tensor(np.where(vid >= 0, vid, 0), device=dev)
+    pt = torch.as_tensor(np.where(pid >= 0, pid, 0), device=dev)
+    vreal = torch.as_tensor(vid >= 0, device=dev)[:, None]
+    preal = torch.as_tensor(pid >= 0, device=dev)
+    results[rank] = dict(
+        eu=float(((u_p - u_g[vt]) * vreal).abs().max() / u_g.abs().max()),
+        ep=float(((p_p - p_g[pt]) * preal).abs().max() / p_g.abs().max()),
+        its=(aux['u_star_info']['num_iterations'],
+             aux['dp_info']['num_iterations']))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_partitioned_navier_stokes_matches_single_rank():
+  """Two ranks, mesh periodic across the cut: two BDF2/EXT1 Navier-Stokes steps
+  (fused H, D, D^T, E, C, filter; all-reduced inner products) equal the
+  one-rank run."""
+  world, port = 2, _free_port()
+  with mp.Manager() as mgr:
+    results = mgr.dict()
+    mp.spawn(_ns_worker, args=(world, port, 4, results), nprocs=world,
+             join=True)
+    res = dict(results)
+  assert sorted(res) == list(range(world))
+  for r in range(world):
+    assert res[r]['eu'] < 1e-8 and res[r]['ep'] < 1e-7, res[r]
+    assert res[r]['its'] == res[0]['its']
