@@ -339,6 +339,14 @@ int sfem_dot(const void* a, const void* b, int64_t count, double* result,
              int dtype, sfem_stream_t stream);
 int sfem_dot_accumulate(const void* a, const void* b, int64_t count,
                         double* result, int dtype, sfem_stream_t stream);
+/* *result += scale * sum_i w[i] * sum_k a[idx[i], k] b[idx[i], k]: the interface
+ * correction that turns the plain local dot of two partition-consistent
+ * vectors into this rank's share of the global inner product (scale = -1,
+ * w = 1 - 1/holders).  a, b: (N,) or (N, ncomp) views with the given strides. */
+int sfem_dot_indexed(const void* a, const void* b, const int64_t* idx,
+                     const double* w, int64_t count, int ncomp,
+                     int64_t node_stride, int64_t comp_stride, double scale,
+                     double* result, int dtype, sfem_stream_t stream);
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
                     double atol, double* partials, sfem_stream_t stream);
 int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,

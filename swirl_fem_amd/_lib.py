@@ -85,6 +85,8 @@ SIGNATURES = {
     'sfem_helmholtz_local': [ctypes.POINTER(HelmholtzArgs), c_ptr],
     'sfem_dot': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_dot_accumulate': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+    'sfem_dot_indexed': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64,
+                         c_i64, c_dbl, c_ptr, c_i32, c_ptr],
     'sfem_cg_scalars': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr, c_ptr],
     'sfem_cg_update_xr': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32,
                           c_i32, c_ptr],

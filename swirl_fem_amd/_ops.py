@@ -537,6 +537,20 @@ def dot(a, b, result, slot, accumulate=False):
                   _dtype_code(a), _stream(dev)), 'sfem_dot')
 
 
+def dot_indexed(a, b, idx, w, result, slot, scale):
+  """result[slot] += scale * sum_i w[i] <a[idx[i]], b[idx[i]]>."""
+  ncomp, ns, cs = _node_view(a)
+  if _node_view(b) != (ncomp, ns, cs) or a.dtype != b.dtype:
+    raise ValueError('dot_indexed: operands must share layout and dtype')
+  flat = lambda t: t.movedim(-1, 0) if is_component_major(t) else t
+  dev = _dev(flat(a), flat(b), idx, w, result)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_dot_indexed(
+        _ptr(a), _ptr(b), _ptr(idx), _ptr(w), idx.numel(), ncomp, ns, cs,
+        float(scale), result.data_ptr() + 8 * slot, _dtype_code(a),
+        _stream(dev)), 'sfem_dot_indexed')
+
+
 def cg_scalars(scalars, phase, maxiter, tol, atol, partials=None):
   dev = _dev(scalars, partials)
   with torch.cuda.device(dev):

@@ -238,6 +238,29 @@ dot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t count,
 
 // scalars (16 doubles): [0] gamma [1] p.Ap [2] gamma_new [3] alpha [4] beta
 //   [5] b.b [6] atol2 [7] done flag (0/1) [8] iterations
+// result += scale * sum_i w[i] a[idx[i]] b[idx[i]]  over a short index list
+// (the interface correction of the partitioned CG inner products).
+template <typename T>
+__global__ void __launch_bounds__(256)
+dot_indexed_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                   const int64_t* __restrict__ idx,
+                   const double* __restrict__ w, int64_t count, int ncomp,
+                   int64_t node_stride, int64_t comp_stride, double scale,
+                   double* __restrict__ result) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride) {
+    const int64_t k = idx[i] * node_stride;
+    double s = 0.0;
+    for (int c = 0; c < ncomp; ++c)
+      s += (double)a[k + c * comp_stride] * (double)b[k + c * comp_stride];
+    acc += w[i] * s;
+  }
+  const double total = block_sum(acc);
+  if (threadIdx.x == 0 && total != 0.0) unsafeAtomicAdd(result, scale * total);
+}
+
 template <typename T, bool FUSE_RR>
 __global__ void __launch_bounds__(512)
 cg_update_xr_kernel(T* __restrict__ x, T* __restrict__ r,
@@ -643,6 +666,22 @@ int sfem_dot_accumulate(const void* a, const void* b, int64_t count,
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
       dot_kernel<T>, dim3(reduce_grid(count, 512 * 4)), dim3(512), 0,
       as_stream(stream), (const T*)a, (const T*)b, count, result));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_dot_indexed(const void* a, const void* b, const int64_t* idx,
+                     const double* w, int64_t count, int ncomp,
+                     int64_t node_stride, int64_t comp_stride, double scale,
+                     double* result, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && ncomp >= 1 && result,
+               "sfem_dot_indexed: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(a && b && idx && w, "sfem_dot_indexed: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      dot_indexed_kernel<T>, dim3(reduce_grid(count, 256)), dim3(256), 0,
+      as_stream(stream), (const T*)a, (const T*)b, idx, w, count, ncomp,
+      node_stride, comp_stride, scale, result));
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

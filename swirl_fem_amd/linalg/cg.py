@@ -70,17 +70,8 @@ class _Scalars:
     idx, w = interface
     if idx.numel() == 0:
       return
-    tot = None
     for x, y in zip(_leaves(a), _leaves(b)):
-      xs = x.index_select(0, idx).to(torch.float64)
-      ys = xs if y is x else layout.like(y, x).index_select(0, idx).to(
-          torch.float64)
-      prod = xs * ys
-      if prod.dim() > 1:
-        prod = prod.reshape(prod.shape[0], -1).sum(dim=1)
-      t = torch.dot(prod, w)
-      tot = t if tot is None else tot + t
-    self.t[slot] -= tot
+      _ops.dot_indexed(x, layout.like(y, x), idx, w, self.t, slot, -1.0)
 
   def dot_into(self, slot, a, b, dot_fn, reduce_fn, interface=None):
     """scalars[slot] = <a, b> summed over the leaves of the pytrees."""
