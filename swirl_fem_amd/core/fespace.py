@@ -332,19 +332,24 @@ class FiniteElementSpace:
     rounding).
     """
     from swirl_fem_amd.core import operators
+    # cached per (mask object, options); the entry keeps the mask alive so that
+    # its id cannot be recycled by another tensor
     key = ('helmholtz', None if dirichlet_mask is None else id(dirichlet_mask),
            geometry, assembly)
-    if key not in self._cache:
-      if not self.is_collocated and assembly == 'atomic' and (
-          operators.supports_two_grid(self) is None):
-        # quadrature != nodes: interpolate, fused element kernel on the
-        # quadrature grid, transposed interpolation
-        self._cache[key] = operators.TwoGridHelmholtzOperator.create(
-            self, dirichlet_mask, 'stored' if geometry == 'stored' else 'auto')
-      else:
-        self._cache[key] = operators.HelmholtzOperator.create(
-            self, dirichlet_mask, geometry, assembly)
-    return self._cache[key]
+    hit = self._cache.get(key)
+    if hit is not None and hit[0] is dirichlet_mask:
+      return hit[1]
+    if not self.is_collocated and assembly == 'atomic' and (
+        operators.supports_two_grid(self) is None):
+      # quadrature != nodes: interpolate, fused element kernel on the
+      # quadrature grid, transposed interpolation
+      op = operators.TwoGridHelmholtzOperator.create(
+          self, dirichlet_mask, 'stored' if geometry == 'stored' else 'auto')
+    else:
+      op = operators.HelmholtzOperator.create(self, dirichlet_mask, geometry,
+                                              assembly)
+    self._cache[key] = (dirichlet_mask, op)
+    return op
 
 
 def _device_matrices(interpolator, dtype, device, cache):
