@@ -23,6 +23,7 @@ How it runs here
 from __future__ import annotations
 
 import dataclasses
+from typing import Protocol
 
 import numpy as np
 import torch
@@ -37,6 +38,24 @@ from swirl_fem_amd.core import qexpr
 
 
 # ---------------------------------------------------------------- q-functions
+class QFunction(Protocol):
+  """A function from the mesh to R^k, called on the point variable `x`
+  (reference core/fespace.py:35-56).  Here `x` is a `QExpr` carrying all
+  quadrature points of all elements at once, and so is the result."""
+
+  def __call__(self, x):
+    ...
+
+
+class Form(Protocol):
+  """Maps q-functions to the scalar q-function that gets integrated
+  (reference core/fespace.py:59-72), e.g.
+  `lambda u, v: lambda x: torch.vdot(grad(u)(x), grad(v)(x))`."""
+
+  def __call__(self, *args: QFunction) -> QFunction:
+    ...
+
+
 @dataclasses.dataclass(eq=False)
 class NodalQFunction:
   """A nodal function of a `FiniteElementSpace` (u_local None = placeholder)."""

@@ -24,6 +24,8 @@ from swirl_fem_amd.core.interpolation import Quadrature1D
 from swirl_fem_amd.core.mesh import Mesh
 from swirl_fem_amd.linalg.cg import cg
 
+Scalar = Any
+Array = Any
 BCValue = Union[Any, Callable]
 
 # pylint: disable=invalid-name
