@@ -204,10 +204,10 @@ class StokesVelocity:
     """(N, d) -> (E, n, d)."""
     return _ops.gather_rows(u, self.mesh.elements)
 
-  def scatter(self, u_local):
+  def scatter(self, u):
     """(E, n, d) -> (N, d)."""
-    return _ops.scatter_add(u_local, self.mesh.elements, self.mesh.num_nodes,
-                            ncomp=u_local.shape[-1])
+    return _ops.scatter_add(u, self.mesh.elements, self.mesh.num_nodes,
+                            ncomp=u.shape[-1])
 
   def exchange(self, u, inplace=False):
     """Apply QQ^T to every component (`inplace`: `u` may be overwritten)."""
