@@ -1,10 +1,21 @@
 """Fused element operators (build-side fast paths behind the reference API).
 
-`HelmholtzOperator` is the collocated  H = lambda0 * B + lambda1 * A  operator
-of the reference's callers -- examples/poisson.py:141-154 (A, B),
-navier_stokes/navier_stokes.py:220-236, :295-307, :431 -- as ONE kernel:
-gather, sum-factorised apply with 6 (+1) stored geometric factors per point,
-Dirichlet mask and direct-stiffness summation (`sfem_helmholtz_apply`).
+* `HelmholtzOperator`: the collocated  H = lambda0 * B + lambda1 * A  of the
+  reference's callers -- examples/poisson.py:141-154 (A, B),
+  navier_stokes/navier_stokes.py:220-236, :295-307, :431 -- as ONE kernel:
+  gather, sum-factorised apply, Dirichlet mask and direct-stiffness summation
+  (`sfem_helmholtz_apply`).  The geometric factors of affine / multilinear
+  elements are evaluated in registers, curved elements read 6 (+1) stored
+  factors per point (`classify_geometry`).
+* `TwoGridHelmholtzOperator`: the same operator when the quadrature differs
+  from the nodes (interpolate -> fused kernel on the quadrature grid ->
+  transposed interpolation).
+* `StokesDivGrad`: D and D^T of the P_N - P_{N-2} pair (navier_stokes.py:
+  313-338), one kernel each.
+* `ConvectionOperator`: the over-integrated convection term (:238-245).
+
+Every class has a `supports_*` predicate; callers fall back to the generic
+q-function path (`FiniteElementSpace.local_covector`) when it says no.
 """
 
 from __future__ import annotations
