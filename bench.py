@@ -116,6 +116,10 @@ def main():
                   help='Helmholtz operator mass_coeff * B + A (0 = Laplacian)')
   ap.add_argument('--tile', type=int, default=0,
                   help='visit elements in tile^3 blocks (0 = lexicographic)')
+  ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                  help="'weak' (default): --elems^3 elements per GPU; 'strong': "
+                       'a fixed --elems^3 mesh split over the GPUs (blocks of '
+                       'elems/px x elems/py x elems/pz elements)')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'gloo' rehearses the N>1 path with all ranks on the "
                        'visible GPU(s) (interface buffers staged via host)')
@@ -161,7 +165,15 @@ def main():
   from swirl_fem_amd.distributed import blocks
   tdtype = torch.float64 if args.dtype == 'f64' else torch.float32
   sizeof = 8 if args.dtype == 'f64' else 4
-  part = blocks.build_block_partition(args.n, P, block_grid(world), rank,
+  grid_b = block_grid(world)
+  if args.scaling == 'strong':
+    if any(args.n % g for g in grid_b):
+      raise SystemExit(f'--elems {args.n} is not divisible by the block grid '
+                       f'{grid_b}')
+    block_n = tuple(args.n // g for g in grid_b)
+  else:
+    block_n = args.n
+  part = blocks.build_block_partition(block_n, P, grid_b, rank,
                                       device=device, jitter=args.jitter,
                                       dtype=tdtype, tile=args.tile)
   mesh = part.mesh
@@ -295,13 +307,14 @@ def main():
         'value': value, 'unit': 'GDOF/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype,
         'data': 'synthetic',
         'config': {
-            'workload': '3D %s CG iteration, %d^3 hex elements per GPU, '
+            'workload': '3D %s CG iteration, %d^3 hex elements %s, '
                         'p=%d GLL collocated, %s, Dirichlet' % (
                             'Helmholtz' if args.mass_coeff else 'Laplacian',
-                            args.n, args.p, args.dtype),
+                            args.n, 'per GPU' if args.scaling == 'weak'
+                            else 'in total', args.p, args.dtype),
             'elements_per_gpu': E, 'dofs_global': N_global,
             'blocks': 'x'.join(map(str, block_grid(world))),
             'partitioned_cg': (args.partitioned + (

@@ -14,3 +14,8 @@ for mode in consistent reference; do
 done
 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --n 32 --no-cpu-baseline --no-general > gpurun_out/part_bench_single.log 2>&1
 tail -1 gpurun_out/part_bench_single.log
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 \
+  --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 4 --steps 10 \
+  --warmup 3 --elems 32 --backend gloo --scaling strong --no-cpu-baseline \
+  > gpurun_out/part_bench_strong.log 2>&1
+echo "bench strong exit $?"; tail -1 gpurun_out/part_bench_strong.log | cut -c1-400

@@ -24,7 +24,7 @@ import itertools
 import numpy as np
 import torch
 
-from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+from swirl_fem_amd.common.premesh_commons import box_mesh
 from swirl_fem_amd.core.interpolation import Nodes1D
 from swirl_fem_amd.core.interpolation import NodeType
 from swirl_fem_amd.core.mesh import Mesh
@@ -46,28 +46,31 @@ class BlockPartition:
     return comm.all_reduce_sum_(t)
 
 
-def tiled_element_order(n: int, ndim: int, tile: int) -> np.ndarray:
-  """Permutation of the C-ordered `n^ndim` elements that visits them tile by
-  tile (`tile^ndim` elements each).  Elements that share faces are then close
-  in the launch order *and* (through the refiner's first-touch numbering) in
-  memory, which shortens the reuse distance of the gathered nodal values."""
-  idx = np.arange(n ** ndim).reshape([n] * ndim)
-  nt = -(-n // tile)
+def tiled_element_order(n, ndim: int, tile: int) -> np.ndarray:
+  """Permutation of the C-ordered elements of an `n[0] x .. x n[d-1]` block
+  (`n` an int = cube) that visits them tile by tile (`tile^ndim` elements
+  each).  Elements that share faces are then close in the launch order *and*
+  (through the refiner's first-touch numbering) in memory, which shortens the
+  reuse distance of the gathered nodal values."""
+  ns = (n,) * ndim if np.isscalar(n) else tuple(n)
+  idx = np.arange(int(np.prod(ns))).reshape(ns)
   out = []
-  for t in np.ndindex(*([nt] * ndim)):
-    sl = tuple(slice(ti * tile, min((ti + 1) * tile, n)) for ti in t)
+  for t in np.ndindex(*[-(-k // tile) for k in ns]):
+    sl = tuple(slice(ti * tile, min((ti + 1) * tile, k))
+               for ti, k in zip(t, ns))
     out.append(idx[sl].reshape(-1))
   return np.concatenate(out)
 
 
-def build_block_partition(n: int, P: int, block_grid, rank: int, *,
+def build_block_partition(n, P: int, block_grid, rank: int, *,
                           device=None, dtype=torch.float64, lo=0.0, hi=1.0,
                           jitter: float = 0.0,
                           tile: int = 0) -> BlockPartition:
   """This rank's block of the `(n*px, n*py, n*pz)`-element mesh on [lo,hi]^3.
 
   Args:
-    n: elements per direction in one block.
+    n: elements per direction in one block: an int, or one count per
+      direction (strong scaling splits a fixed mesh into non-cubic blocks).
     P: GLL nodes per direction (order + 1).
     block_grid: (px, py, pz) blocks; rank = C-order ravel of block coords.
     jitter: optional smooth deformation amplitude (fraction of h), identical on
@@ -75,40 +78,45 @@ def build_block_partition(n: int, P: int, block_grid, rank: int, *,
   """
   ndim = len(block_grid)
   block_grid = tuple(int(p) for p in block_grid)
+  ns = (int(n),) * ndim if np.isscalar(n) else tuple(int(k) for k in n)
+  if len(ns) != ndim:
+    raise ValueError(f'n has {len(ns)} entries for a {ndim}-d block grid')
   coords_b = tuple(int(c) for c in np.unravel_index(rank, block_grid))
-  pm = unit_cube_mesh(n, ndim=ndim)
+  pm = box_mesh(ns, (0.0,) * ndim, (1.0,) * ndim)
   # affine map of the unit block into its slot of the global box
   x = np.array(pm.node_coords)
   for d in range(ndim):
     x[:, d] = lo + (hi - lo) * (coords_b[d] + x[:, d]) / block_grid[d]
   if jitter:
-    h = (hi - lo) / (n * max(block_grid))
+    h = (hi - lo) / max(k * g for k, g in zip(ns, block_grid))
     s = np.ones(len(x))
     for d in range(ndim):
       s = s * np.sin(np.pi * (x[:, d] - lo) / (hi - lo))
     x = x + jitter * h * s[:, None] * np.cos(
         2 * np.pi * x[:, ::-1] / (hi - lo))
-  # keep only the faces that lie on the global boundary
-  nf = n ** (ndim - 1)
-  faces = pm.physical_groups['boundary'].reshape(ndim, 2, nf, -1)
-  keep = []
+  # keep only the faces that lie on the global boundary (the group lists, per
+  # axis, the FIRST side then the LAST side)
+  bfaces, at, keep = pm.physical_groups['boundary'], 0, []
   for d in range(ndim):
+    nf = int(np.prod([ns[a] for a in range(ndim) if a != d]))
+    first, last = bfaces[at:at + nf], bfaces[at + nf:at + 2 * nf]
+    at += 2 * nf
     if coords_b[d] == 0:
-      keep.append(faces[d, 0])
+      keep.append(first)
     if coords_b[d] == block_grid[d] - 1:
-      keep.append(faces[d, 1])
+      keep.append(last)
   groups = {'boundary': np.concatenate(keep)} if keep else {}
   pm = pm.replace(node_coords=x, physical_groups=groups)
   perm = None
-  if tile and tile < n:
-    perm = tiled_element_order(n, ndim, tile)
+  if tile and tile < max(ns):
+    perm = tiled_element_order(ns, ndim, tile)
     pm = pm.replace(elements=pm.elements[perm])
   rp = refine_premesh(pm, Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE))
 
   # block-local GLL lattice coordinates of every local node
   m = P - 1
-  L = n * m                                   # last lattice index per dim
-  ecoord = np.stack(np.meshgrid(*([np.arange(n)] * ndim), indexing='ij'),
+  L = np.array(ns, dtype=np.int64) * m        # last lattice index per dim
+  ecoord = np.stack(np.meshgrid(*[np.arange(k) for k in ns], indexing='ij'),
                     axis=-1).reshape(-1, ndim)              # (E, d)
   if perm is not None:
     ecoord = ecoord[perm]
@@ -120,7 +128,7 @@ def build_block_partition(n: int, P: int, block_grid, rank: int, *,
     vals = (ecoord[:, None, d] * m + lcoord[None, :, d]).reshape(-1)
     lat[flat, d] = vals
   glob = lat.astype(np.int64) + np.array(coords_b, dtype=np.int64) * L
-  gdims = [block_grid[d] * L + 1 for d in range(ndim)]
+  gdims = [int(block_grid[d] * L[d] + 1) for d in range(ndim)]
   key = np.ravel_multi_index(tuple(glob[:, d] for d in range(ndim)), gdims)
 
   neighbors, indices = [], []
@@ -135,7 +143,7 @@ def build_block_partition(n: int, P: int, block_grid, rank: int, *,
       if o == -1:
         sel &= lat[:, d] == 0
       elif o == 1:
-        sel &= lat[:, d] == L
+        sel &= lat[:, d] == L[d]
     pos = np.nonzero(sel)[0]
     pos = pos[np.argsort(key[pos], kind='stable')]
     neighbors.append(int(np.ravel_multi_index(nb, block_grid)))

@@ -60,7 +60,10 @@ def _worker(rank, world, port, grid, n, P, results):
 
 
 @pytest.mark.parametrize('grid,n,P', [((2, 1, 1), 2, 3), ((2, 2, 1), 2, 4),
-                                      ((2, 1), 3, 4)])
+                                      ((2, 1), 3, 4),
+                                      # non-cubic blocks (strong scaling)
+                                      ((2, 1, 1), (1, 2, 2), 3),
+                                      ((2, 2), (2, 3), 4)])
 def test_neighbor_exchange_gloo(grid, n, P):
   world = int(np.prod(grid))
   port = _free_port()
