@@ -96,7 +96,12 @@ class Premesh:
         periodic_links=self.periodic_links)
     masks = {k: _mask(f, node_indices)
              for k, f in self.physical_groups.items()}
-    gi, ui = gather_scatter.get_exchange_indices(node_indices)
+    if self.periodic_links is None:
+      # every node is its own class: nothing to exchange (what the general
+      # routine returns after sorting all N ids)
+      gi, ui = np.zeros(0, np.int32), np.zeros(0, np.int32)
+    else:
+      gi, ui = gather_scatter.get_exchange_indices(node_indices)
     return dict(node_coords=self.node_coords, elements=self.elements,
                 node_indices=node_indices, physical_masks=masks,
                 exchange_gather_indices=gi, exchange_unique_indices=ui)
