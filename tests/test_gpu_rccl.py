@@ -29,7 +29,10 @@ def rccl():
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   torch.cuda.set_device(0)
-  dist.init_process_group('nccl', rank=0, world_size=1, device_id=DEV)
+  try:
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=DEV)
+  except Exception as e:     # pylint: disable=broad-except
+    pytest.skip(f'RCCL communicator could not be created here: {e}')
   yield
   dist.destroy_process_group()
 
