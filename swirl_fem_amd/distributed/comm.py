@@ -11,7 +11,8 @@ point-to-point links of a GPU are used in parallel:
     pack (HIP gather)  ->  grouped ncclSend/ncclRecv  ->  unpack-add (HIP)
 
 One process owns one partition (`torch.distributed`, backend "nccl" = RCCL on
-ROCm; "gloo" in the CPU tests).  The result is bit-for-bit QQ^T u: every rank
+ROCm; the CPU tests drive `exchange_buffers` over "gloo" and do the pack /
+unpack halves with the oracle on their side).  The result is bit-for-bit QQ^T u: every rank
 adds the *original* values of all other holders of a DOF to its own.
 """
 
@@ -130,25 +131,18 @@ def exchange_buffers(plan: NeighborPlan, send_bufs, group=None,
   return recv_bufs
 
 
-def neighbor_exchange(u: torch.Tensor, plan: NeighborPlan, group=None, *,
-                      pack_fn=None, unpack_add_fn=None) -> torch.Tensor:
-  """QQ^T u for this rank's partition.
-
-  `pack_fn` / `unpack_add_fn` default to the HIP kernels (`sfem_pack`,
-  `sfem_unpack_add`); they exist as parameters only so that the CPU (gloo)
-  tests can exercise the communication pattern with the oracle's gather /
-  scatter as the checker.
-  """
-  if pack_fn is None or unpack_add_fn is None:
-    from swirl_fem_amd import _ops
-    pack_fn = pack_fn or _ops.pack
-    unpack_add_fn = unpack_add_fn or _ops.unpack_add
+def neighbor_exchange(u: torch.Tensor, plan: NeighborPlan,
+                      group=None) -> torch.Tensor:
+  """QQ^T u for this rank's partition, as a new tensor (`sfem_pack` per
+  neighbour -> grouped send/recv -> `sfem_unpack_add`).  Device tensors only:
+  the pack / unpack halves are HIP kernels and nothing else."""
+  from swirl_fem_amd import _ops
   idx = plan.device_indices(u.device)
-  send = [pack_fn(u, ix) for ix in idx]
+  send = [_ops.pack(u, ix) for ix in idx]
   recv = exchange_buffers(plan, send, group=group)
   out = u.clone()
   for rb, ix in zip(recv, idx):
-    unpack_add_fn(rb, ix, out)
+    _ops.unpack_add(rb, ix, out)
   return out
 
 

@@ -2,9 +2,9 @@
 
 One process per partition, `torch.distributed` with the gloo backend.  The
 product's communication code (`NeighborPlan`, `exchange_buffers`,
-`neighbor_exchange`, `all_reduce_sum_`) runs unchanged; the pack / unpack-add
-halves, which are HIP kernels in production, are supplied by the oracle's
-gather / scatter through the test hooks of `neighbor_exchange`.
+`all_reduce_sum_`) runs unchanged; the pack / unpack-add halves around it are
+HIP kernels in the product (`neighbor_exchange`, GPU tests), so here the test
+does them itself with the oracle's gather / scatter.
 """
 import os
 import socket
@@ -44,8 +44,11 @@ def _worker(rank, world, port, grid, n, P, results):
     assert comm.get_rank() == rank and comm.get_world_size() == world
     rng = np.random.default_rng(100 + rank)
     u = torch.from_numpy(rng.standard_normal(part.mesh.num_nodes))
-    out = comm.neighbor_exchange(u, part.plan, pack_fn=_oracle_pack,
-                                 unpack_add_fn=_oracle_unpack_add)
+    idx = [torch.as_tensor(ix) for ix in part.plan.indices]
+    recv = comm.exchange_buffers(part.plan, [_oracle_pack(u, ix) for ix in idx])
+    out = u.clone()
+    for rb, ix in zip(recv, idx):
+      _oracle_unpack_add(rb, ix, out)
     # Mesh.exchange routes to the same call in the partitioned case
     assert part.mesh.axis_name == 'blocks'
     assert part.mesh.neighbor_plan is part.plan
