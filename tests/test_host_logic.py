@@ -235,6 +235,44 @@ def test_refiner_random_orientations():
       assert bad_reference > 0        # documents the upstream defect
 
 
+@pytest.mark.parametrize('mode', ['corrected', 'reference'])
+def test_refiner_common_facet_reference_cases(mode):
+  """core/mesh_refiner_test.py:87-133 and :180-228: a second element whose
+  vertex order shows the common facet reversed (2D) / rotated (3D)."""
+  import itertools
+  from swirl_fem_amd.core.premesh import Premesh
+  nc = I.Nodes1D.create(3, NT['nc'])
+  # 2D: elements [0,1,2,3], [3,5,2,4]
+  xy = np.array(list(itertools.product([0, 1, 2], [0, 1])), dtype=np.float32)
+  pm = Premesh.create(node_coords=xy, elements=np.array(
+      [[0, 1, 2, 3], [3, 5, 2, 4]], dtype=np.int32))
+  rp = refine_premesh(pm, nc, face_orientation=mode)
+  right = rp.elements[0].reshape(3, 3)[-1, :].flatten()
+  left = rp.elements[1].reshape(3, 3)[:, 0].flatten()
+  assert len(right) == 3 and set(right) == set(left)
+  np.testing.assert_array_almost_equal(
+      rp.node_coords[right],
+      np.array(list(itertools.product([1.0], [0.0, 0.5, 1.0]))))
+  # 3D: elements [0..7], [5,7,4,6,9,11,8,10] (common face rotated by 90 deg)
+  xyz = np.array(list(itertools.product([0, 1, 2], [0, 1], [0, 1])),
+                 dtype=np.float32)
+  pm = Premesh.create(node_coords=xyz, elements=np.array(
+      [[0, 1, 2, 3, 4, 5, 6, 7], [5, 7, 4, 6, 9, 11, 8, 10]], dtype=np.int32))
+  rp = refine_premesh(pm, nc, face_orientation=mode)
+  right = rp.elements[0].reshape(3, 3, 3)[-1].flatten()
+  left = rp.elements[1].reshape(3, 3, 3)[0].flatten()
+  assert len(right) == 9 and set(right) == set(left)
+  np.testing.assert_array_almost_equal(
+      rp.node_coords[right], np.array(list(itertools.product(
+          [1.0], [0.0, 0.5, 1.0], [0.0, 0.5, 1.0]))))
+  # with two interior nodes per direction the rotation matters: only the
+  # corrected read-back keeps both elements the images of their vertices
+  gll4 = I.Nodes1D.create(4, NT['gll'])
+  rp4 = refine_premesh(pm, gll4, face_orientation=mode)
+  err = _multilinear_error(pm, rp4, gll4)
+  assert bool((err < 1e-6).all()) == (mode == 'corrected'), err
+
+
 def test_unit_cube_mesh_counts():
   # common/premesh_commons_test.py:26-48
   for ndim in (1, 2, 3):
