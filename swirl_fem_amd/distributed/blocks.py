@@ -40,6 +40,7 @@ class BlockPartition:
   block_coords: tuple
   num_global_nodes: int
   plan: comm.NeighborPlan
+  global_keys: np.ndarray | None = None   # global GLL lattice key per node
 
   def reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
     """All-reduce of CG scalars across the partitions (RCCL)."""
@@ -167,4 +168,5 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
                                if world > 1 and indices else None))
   return BlockPartition(mesh=mesh, rank=rank, block_grid=block_grid,
                         block_coords=coords_b,
-                        num_global_nodes=int(np.prod(gdims)), plan=plan)
+                        num_global_nodes=int(np.prod(gdims)), plan=plan,
+                        global_keys=key.astype(np.int64))

@@ -116,3 +116,79 @@ def test_plan_matches_reference_style_gather_indices():
       out[ix] += us[q][plans[q].indices[j]]
     np.testing.assert_allclose(out, ref[r], rtol=0, atol=1e-14)
     assert plan.num_shared == sum(len(i) for i in plan.indices)
+
+
+def _router_worker(rank, world, port, results):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from swirl_fem_amd.communication.crystal_router import crystal_router
+    from swirl_fem_amd.communication.pscan import preduce, pscan
+    from swirl_fem_amd.distributed.discover import discover_neighbors
+    rng = np.random.default_rng(50 + rank)
+    n = int(rng.integers(0, 40))
+    target = torch.from_numpy(rng.integers(0, world, n))
+    payload = torch.from_numpy(rng.integers(0, 10 ** 6, (n, 3)))
+    tag = torch.full((n,), rank, dtype=torch.int64)
+    n_out, (pay_o, tag_o), src = crystal_router(None, [payload, tag], target)
+    assert n_out == len(src) and bool((tag_o == src).all())
+    # round trip: everything returns to its sender
+    n_back, (pay_b, tag_b), src_b = crystal_router(n_out, [pay_o, tag_o], src)
+    assert n_back == n and bool((tag_b == rank).all())
+    a = np.sort(pay_b.numpy().view([('', pay_b.numpy().dtype)] * 3), axis=0)
+    b = np.sort(payload.numpy().view([('', payload.numpy().dtype)] * 3), axis=0)
+    assert np.array_equal(a, b)
+    # scans
+    x = torch.tensor([rank + 1, 10 * (rank + 1)], dtype=torch.int64)
+    ex, tot = pscan(x, 'add', reduction=True)
+    assert ex.tolist() == [sum(range(1, rank + 1)),
+                           10 * sum(range(1, rank + 1))]
+    assert tot.tolist() == [sum(range(1, world + 1)),
+                            10 * sum(range(1, world + 1))]
+    assert int(pscan(torch.tensor([rank]), 'maximum')) == (
+        rank - 1 if rank else torch.iinfo(torch.int64).min)
+    assert int(preduce(torch.tensor([rank]), 'maximum')) == world - 1
+    # neighbour discovery == the block builder's lattice-based plan
+    grid = {2: (2, 1, 1), 3: (3, 1), 4: (2, 2, 1), 5: (5, 1)}[world]
+    part = blocks.build_block_partition(2, 3, grid, rank, device='cpu')
+    plan = discover_neighbors(part.global_keys)
+    assert plan.neighbors == part.plan.neighbors, (plan.neighbors,
+                                                   part.plan.neighbors)
+    for i1, i2 in zip(plan.indices, part.plan.indices):
+      np.testing.assert_array_equal(i1, i2)
+    # ... and the reference-style (P, S) table of a partitioned Gmsh mesh
+    from swirl_fem_amd.common import mesh_partitioner, mesh_reader
+    from swirl_fem_amd.core.interpolation import Nodes1D, NodeType
+    from swirl_fem_amd.core.mesh_refiner import refine_premesh
+    pm = mesh_reader.read(os.path.join(os.path.dirname(__file__), 'golden',
+                                       'msh', 'cube.msh'), ndim=3)
+    rp = refine_premesh(mesh_partitioner.partition(pm, world),
+                        Nodes1D.create(3, NodeType.GAUSS_LOBATTO_LEGENDRE))
+    arrs = rp.finalize_all('parts')
+    central = comm.NeighborPlan.from_gather_indices(
+        arrs['exchange_gather_indices'], rank)
+    found = discover_neighbors(arrs['global_node_ids'][rank])
+    assert found.neighbors == central.neighbors
+    for i1, i2 in zip(found.indices, central.indices):
+      np.testing.assert_array_equal(i1, i2)
+    results[rank] = (n, n_out, target.numpy().tolist())
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3, 4, 5])
+def test_crystal_router_pscan_and_discovery(world):
+  """communication/: sparse all-to-all (odd group sizes included), exclusive
+  scan, and the neighbour plan discovered through the router equals the one the
+  block builder derives from lattice coordinates."""
+  port = _free_port()
+  with mp.Manager() as mgr:
+    results = mgr.dict()
+    mp.spawn(_router_worker, args=(world, port, results), nprocs=world,
+             join=True)
+    res = dict(results)
+  assert sorted(res) == list(range(world))
+  # conservation: rank q received exactly what was addressed to it
+  for q in range(world):
+    assert res[q][1] == sum(t.count(q) for _, _, t in res.values())
