@@ -280,3 +280,28 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
     if run.done():
       break
   return run.x, run.info()
+
+
+class _SymmetricSolve(torch.autograd.Function):
+  """x = A^-1 b with the adjoint solved by the same routine (A symmetric)."""
+
+  @staticmethod
+  def forward(ctx, b, A, kwargs):
+    x, info = cg(A, b.detach(), **kwargs)
+    ctx.A, ctx.kwargs = A, kwargs
+    return x
+
+  @staticmethod
+  def backward(ctx, grad_x):
+    # d<x, g>/db = A^-T g = A^-1 g
+    grad_b, _ = cg(ctx.A, grad_x.detach().contiguous(), **ctx.kwargs)
+    return grad_b, None, None
+
+
+def symmetric_solve(A, b, **kwargs):
+  """`cg(A, b, **kwargs)[0]` that autograd can differentiate with respect to
+  `b`: the cotangent is obtained by a second solve with the same symmetric
+  operator, which is what `lax.custom_linear_solve(symmetric=True)` does for
+  the reference's solves (navier_stokes/navier_stokes.py:436-452).  Gradients
+  with respect to tensors hidden inside `A` are not propagated."""
+  return _SymmetricSolve.apply(b, A, kwargs)

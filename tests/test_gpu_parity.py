@@ -725,6 +725,24 @@ def test_cg_update_groupings_agree(dtype):
       assert float(s1[2]) == float(s2[2]) or fuse   # atomics: order may differ
 
 
+def test_symmetric_solve_is_differentiable_in_b():
+  """d/db of <w, A^-1 b> = A^-1 w (adjoint solve with the same operator)."""
+  from swirl_fem_amd.linalg.cg import cg, symmetric_solve
+  rp = make_case(2, 4, 4, jitter=0.1, seed=6)
+  mesh, fes, _ = spaces(rp, 4, 4, 'gll')
+  bm = mesh.physical_masks['boundary']
+  op = fes.helmholtz_operator(bm)
+  A = lambda u: op.apply(u, 0.7, 1.0)
+  rng = np.random.default_rng(7)
+  keep = (~bm).to(torch.float64)
+  b = (dev(rng.standard_normal(mesh.num_nodes)) * keep).requires_grad_(True)
+  w = dev(rng.standard_normal(mesh.num_nodes)) * keep
+  x = symmetric_solve(A, b, tol=1e-13, maxiter=2000)
+  (x * w).sum().backward()
+  want, _ = cg(A, w, tol=1e-13, maxiter=2000)
+  assert float((b.grad - want).abs().max()) < 1e-9 * float(want.abs().max())
+
+
 def test_cg_graph_replay_matches_eager():
   """One HIP graph launch per iteration == the eager launch sequence."""
   from swirl_fem_amd.linalg.cg import cg, CGRunner
