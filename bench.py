@@ -120,6 +120,11 @@ def main():
                   help="'weak' (default): --elems^3 elements per GPU; 'strong': "
                        'a fixed --elems^3 mesh split over the GPUs (blocks of '
                        'elems/px x elems/py x elems/pz elements)')
+  ap.add_argument('--periodic', action='store_true',
+                  help='N>1: the box is periodic in every direction that is '
+                       'split over GPUs (N=8: the triply periodic 2x2x2 box of '
+                       'BASELINE config 4); a fully periodic run solves the '
+                       'Helmholtz problem B + A instead of the singular A')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'gloo' rehearses the N>1 path with all ranks on the "
                        'visible GPU(s) (interface buffers staged via host)')
@@ -173,9 +178,14 @@ def main():
     block_n = tuple(args.n // g for g in grid_b)
   else:
     block_n = args.n
+  periodic_dims = tuple(d for d, g in enumerate(grid_b) if g >= 2) if (
+      args.periodic and world > 1) else ()
+  if len(periodic_dims) == 3 and args.mass_coeff == 0.0:
+    args.mass_coeff = 1.0          # no Dirichlet boundary left: A is singular
   part = blocks.build_block_partition(block_n, P, grid_b, rank,
                                       device=device, jitter=args.jitter,
-                                      dtype=tdtype, tile=args.tile)
+                                      dtype=tdtype, tile=args.tile,
+                                      periodic_dims=periodic_dims)
   mesh = part.mesh
   fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
   op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
@@ -317,6 +327,7 @@ def main():
                             else 'in total', args.p, args.dtype),
             'elements_per_gpu': E, 'dofs_global': N_global,
             'blocks': 'x'.join(map(str, block_grid(world))),
+            'periodic_dims': list(periodic_dims),
             'partitioned_cg': (args.partitioned + (
                 '' if args.no_overlap or args.partitioned != 'consistent'
                 else ', exchange overlapped with interior elements'))

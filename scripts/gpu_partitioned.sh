@@ -19,3 +19,8 @@ timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 
   --warmup 3 --elems 32 --backend gloo --scaling strong --no-cpu-baseline \
   > gpurun_out/part_bench_strong.log 2>&1
 echo "bench strong exit $?"; tail -1 gpurun_out/part_bench_strong.log | cut -c1-400
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+  --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 2 --steps 10 \
+  --warmup 3 --elems 16 --backend gloo --periodic --no-cpu-baseline \
+  > gpurun_out/part_bench_periodic.log 2>&1
+echo "bench periodic exit $?"; grep "^{" gpurun_out/part_bench_periodic.log | cut -c1-500

@@ -65,8 +65,8 @@ def tiled_element_order(n, ndim: int, tile: int) -> np.ndarray:
 
 def build_block_partition(n, P: int, block_grid, rank: int, *,
                           device=None, dtype=torch.float64, lo=0.0, hi=1.0,
-                          jitter: float = 0.0,
-                          tile: int = 0) -> BlockPartition:
+                          jitter: float = 0.0, tile: int = 0,
+                          periodic_dims=()) -> BlockPartition:
   """This rank's block of the `(n*px, n*py, n*pz)`-element mesh on [lo,hi]^3.
 
   Args:
@@ -76,12 +76,26 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
     block_grid: (px, py, pz) blocks; rank = C-order ravel of block coords.
     jitter: optional smooth deformation amplitude (fraction of h), identical on
       all ranks because it is a function of the global coordinates.
+    periodic_dims: directions in which the global box is periodic (config 4:
+      all three).  Needs at least two blocks along each of them, so that no
+      rank holds two images of a node; the neighbour lists then come from the
+      router-based discovery (`distributed/discover.py`, a collective call)
+      on the periodic lattice keys -- a pair of ranks may meet twice, at the
+      cut and through the wrap-around.
   """
   ndim = len(block_grid)
   block_grid = tuple(int(p) for p in block_grid)
   ns = (int(n),) * ndim if np.isscalar(n) else tuple(int(k) for k in n)
   if len(ns) != ndim:
     raise ValueError(f'n has {len(ns)} entries for a {ndim}-d block grid')
+  periodic_dims = tuple(int(d) for d in periodic_dims)
+  for d in periodic_dims:
+    if block_grid[d] < 2:
+      raise NotImplementedError(
+          f'periodic direction {d} needs at least 2 blocks (a rank would hold '
+          'both images of its boundary nodes)')
+  if jitter and periodic_dims:
+    raise NotImplementedError('jitter on a periodic box')
   coords_b = tuple(int(c) for c in np.unravel_index(rank, block_grid))
   pm = box_mesh(ns, (0.0,) * ndim, (1.0,) * ndim)
   # affine map of the unit block into its slot of the global box
@@ -102,6 +116,8 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
     nf = int(np.prod([ns[a] for a in range(ndim) if a != d]))
     first, last = bfaces[at:at + nf], bfaces[at + nf:at + 2 * nf]
     at += 2 * nf
+    if d in periodic_dims:
+      continue
     if coords_b[d] == 0:
       keep.append(first)
     if coords_b[d] == block_grid[d] - 1:
@@ -129,11 +145,21 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
     vals = (ecoord[:, None, d] * m + lcoord[None, :, d]).reshape(-1)
     lat[flat, d] = vals
   glob = lat.astype(np.int64) + np.array(coords_b, dtype=np.int64) * L
-  gdims = [int(block_grid[d] * L[d] + 1) for d in range(ndim)]
+  gdims = [int(block_grid[d] * L[d] + (0 if d in periodic_dims else 1))
+           for d in range(ndim)]
+  for d in periodic_dims:
+    glob[:, d] %= gdims[d]                    # x = hi is the image of x = lo
   key = np.ravel_multi_index(tuple(glob[:, d] for d in range(ndim)), gdims)
 
   neighbors, indices = [], []
+  if periodic_dims:
+    from swirl_fem_amd.distributed import discover
+    found = discover.discover_neighbors(
+        key, device=device if comm.dist.get_backend() == 'nccl' else 'cpu')
+    neighbors, indices = list(found.neighbors), list(found.indices)
   for off in itertools.product((-1, 0, 1), repeat=ndim):
+    if periodic_dims:
+      break
     if not any(off):
       continue
     nb = tuple(c + o for c, o in zip(coords_b, off))

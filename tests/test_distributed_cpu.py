@@ -192,3 +192,52 @@ def test_crystal_router_pscan_and_discovery(world):
   # conservation: rank q received exactly what was addressed to it
   for q in range(world):
     assert res[q][1] == sum(t.count(q) for _, _, t in res.values())
+
+
+def _periodic_worker(rank, world, port, grid, per, n, P, results):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    part = blocks.build_block_partition(n, P, grid, rank, device='cpu',
+                                        periodic_dims=per)
+    rng = np.random.default_rng(200 + rank)
+    u = torch.from_numpy(rng.standard_normal(part.mesh.num_nodes))
+    idx = [torch.as_tensor(ix) for ix in part.plan.indices]
+    recv = comm.exchange_buffers(part.plan, [_oracle_pack(u, ix) for ix in idx])
+    out = u.clone()
+    for rb, ix in zip(recv, idx):
+      _oracle_unpack_add(rb, ix, out)
+    has_boundary = 'boundary' in part.mesh.physical_masks
+    results[rank] = (part.global_keys, u.numpy(), out.numpy(),
+                     part.plan.neighbors, has_boundary, part.num_global_nodes)
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('grid,per,n,P', [((2, 1, 1), (0,), 2, 3),
+                                          ((2, 2, 1), (0, 1), 2, 3),
+                                          ((2, 2), (0, 1), (2, 3), 4)])
+def test_periodic_block_partitions(grid, per, n, P):
+  """Blocks of a box that is periodic across the partition cuts (config 4's
+  situation): the neighbour plan comes from the router-based discovery on
+  periodic lattice keys; QQ^T sums every image of a node exactly once."""
+  world = int(np.prod(grid))
+  port = _free_port()
+  with mp.Manager() as mgr:
+    results = mgr.dict()
+    mp.spawn(_periodic_worker, args=(world, port, grid, per, n, P, results),
+             nprocs=world, join=True)
+    res = dict(results)
+  tot = {}
+  for keys, u, _, _, _, _ in res.values():
+    assert len(np.unique(keys)) == len(keys)      # one image per rank
+    for k, v in zip(keys.tolist(), u):
+      tot[k] = tot.get(k, 0.0) + v
+  assert len(tot) == res[0][5]                    # unique periodic nodes
+  for r, (keys, u, out, neighbors, has_boundary, _) in res.items():
+    np.testing.assert_allclose(out, [tot[k] for k in keys.tolist()],
+                               rtol=0, atol=1e-13)
+    assert has_boundary == (len(per) < len(grid))
+  if grid == (2, 1, 1):
+    assert res[0][3] == [1] and res[1][3] == [0]  # one neighbour, met twice
