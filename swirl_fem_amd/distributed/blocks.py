@@ -41,6 +41,7 @@ class BlockPartition:
   num_global_nodes: int
   plan: comm.NeighborPlan
   global_keys: np.ndarray | None = None   # global GLL lattice key per node
+  premesh: object = None                  # the block's order-1 premesh
 
   def reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
     """All-reduce of CG scalars across the partitions (RCCL)."""
@@ -195,4 +196,4 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
   return BlockPartition(mesh=mesh, rank=rank, block_grid=block_grid,
                         block_coords=coords_b,
                         num_global_nodes=int(np.prod(gdims)), plan=plan,
-                        global_keys=key.astype(np.int64))
+                        global_keys=key.astype(np.int64), premesh=pm)

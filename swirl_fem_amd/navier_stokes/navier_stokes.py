@@ -10,8 +10,10 @@ over-integrated on GLL(order+1+2) points.
 
 Kernels: the velocity stiffness / mass / Helmholtz operators run the fused
 gather-apply-scatter kernel (`sfem_helmholtz_apply`, all components in one
-launch); convection, divergence and its transpose, the pressure mass matrix and
-the filter go through the generic sum-factorised basis kernels
+launch), divergence and pressure gradient `sfem_stokes_div` /
+`sfem_stokes_grad_t`, convection `sfem_stokes_convect_local` between two
+interpolations; the pressure mass matrix and the filter go through the
+two-grid / generic sum-factorised basis kernels
 (`sfem_basis_eval`, `sfem_basis_eval_t`); both PCG solves of a time step use
 the device-resident CG (`linalg/cg.py`).  `lax.custom_linear_solve` of the
 reference (:436-452) only matters for differentiation through the solve and is
@@ -97,6 +99,9 @@ def dirichlet_bc(mesh: Mesh, boundary_conditions) -> torch.Tensor:
   interior_mask = torch.ones(mesh.num_nodes, dtype=mesh.dtype,
                              device=mesh.device)
   for physical_group, (bctype, unused_bcvalue) in boundary_conditions.items():
+    if physical_group not in mesh.physical_masks and (
+        mesh.axis_name is not None or mesh.neighbor_plan is not None):
+      continue           # this rank's block does not touch that boundary
     if bctype == BCType.DIRICHLET:
       interior_mask = interior_mask * (
           1 - mesh.physical_masks[physical_group].to(mesh.dtype))
@@ -157,11 +162,22 @@ class StokesVelocity:
   @classmethod
   def create(cls, premesh: Premesh, order: int, boundary_conditions,
              num_convection_overint_nodes: int = 2, device=None,
-             dtype=None, axis_name=None, rank=None) -> 'StokesVelocity':
+             dtype=None, axis_name=None, rank=None,
+             neighbor_plan=None) -> 'StokesVelocity':
     gridpoints_1d = Nodes1D.create(
         num_points=order + 1, node_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
     vmesh = refine_premesh(premesh, gridpoints_1d=gridpoints_1d).finalize(
         axis_name, rank=rank, device=device, dtype=dtype)
+    if neighbor_plan is not None:
+      # `premesh` is this rank's own block (distributed/blocks.py): the
+      # refined block mesh numbers its nodes exactly like the block builder's
+      # mesh, so the builder's neighbour plan applies as it is
+      cat = (np.concatenate(neighbor_plan.indices).astype(np.int32)
+             if neighbor_plan.indices else np.zeros(0, np.int32))
+      vmesh = vmesh.replace(
+          axis_name='blocks', neighbor_plan=neighbor_plan,
+          exchange_gather_indices=torch.as_tensor(cat, device=vmesh.device),
+          exchange_unique_indices=None)
     vspace = FiniteElementSpace.create(
         mesh=vmesh, quadrature=Quadrature1D.create_from_nodes_1d(gridpoints_1d))
     interior_mask = dirichlet_bc(vmesh, boundary_conditions)
@@ -289,12 +305,18 @@ class StokesSEM:
   @classmethod
   def create(cls, premesh: Premesh, boundary_conditions, order: int,
              num_convection_overint_nodes: int = 2, *, device=None,
-             dtype=None, axis_name=None, rank=None) -> 'StokesSEM':
+             dtype=None, axis_name=None, rank=None,
+             neighbor_plan=None) -> 'StokesSEM':
     """`axis_name` / `rank`: build this rank's partition of a partitioned
     premesh (one process per GPU; the reference has no partitioned
     Navier-Stokes path).  Fields are then consistent across partitions, right
     hand sides unassembled, `M = exchange` assembles inside the solves and the
-    inner products are all-reduced."""
+    inner products are all-reduced.
+
+    `neighbor_plan`: alternatively `premesh` is already this rank's own block
+    and the plan says which of its nodes other ranks hold too
+    (`BlockPartition.premesh` / `.plan` of `distributed/blocks.py`: nothing of
+    the global mesh is ever built)."""
     if premesh.order != 1:
       raise ValueError(f'Expected mesh order 1; got {premesh.order}.')
     quadrature = Quadrature1D.create(
@@ -305,7 +327,8 @@ class StokesSEM:
     velocity = StokesVelocity.create(premesh, order, boundary_conditions,
                                      num_convection_overint_nodes,
                                      device=device, dtype=dtype,
-                                     axis_name=axis_name, rank=rank)
+                                     axis_name=axis_name, rank=rank,
+                                     neighbor_plan=neighbor_plan)
     ones = torch.ones(velocity.local_shape, dtype=velocity.mesh.dtype,
                       device=velocity.mesh.device)
     velocity_mass_diag = velocity.scatter(velocity.B_local(ones))

@@ -266,3 +266,85 @@ def test_partitioned_navier_stokes_matches_single_rank():
   for r in range(world):
     assert res[r]['eu'] < 1e-8 and res[r]['ep'] < 1e-7, res[r]
     assert res[r]['its'] == res[0]['its']
+
+
+def _ns_blocks_worker(rank, world, port, order, results):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from swirl_fem_amd.common.premesh_commons import box_mesh
+    from swirl_fem_amd.distributed import blocks
+    from swirl_fem_amd.examples.navier_stokes_driver import (
+        _histories, navier_stokes_step)
+    from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
+    dev = torch.device('cuda', 0)
+    bcs = {'boundary': (BCType.DIRICHLET, 0.0)}
+
+    def run(sem):
+      x = sem.velocity.mesh.node_coords
+      wall = torch.sin(np.pi * x[:, 1]) * torch.sin(np.pi * x[:, 2])
+      u0 = torch.stack([torch.sin(2 * np.pi * x[:, 0]) * wall,
+                        torch.cos(2 * np.pi * x[:, 0]) * wall * x[:, 1],
+                        0.5 * wall], dim=-1)
+      p0 = torch.zeros(sem.pressure.pspace.mesh.num_nodes, dtype=x.dtype,
+                       device=dev)
+      us, ps, Cus = _histories(sem, u0, p0, 2)
+      for _ in range(2):
+        u, p, Cu, aux = navier_stokes_step(
+            sem, us, ps, Cus, reynolds=50.0, dt=1e-2, time_order=2,
+            tol=1e-11, atol=0.0)
+        us, ps, Cus = us[1:] + (u,), ps[1:] + (p,), Cus[1:] + (Cu,)
+      return u, p
+
+    # this rank's block only: 2 x 2 x 2 elements of the 4 x 2 x 2 box that is
+    # periodic in x (the two blocks meet at the cut and through the wrap)
+    part = blocks.build_block_partition(2, order + 1, (2, 1, 1), rank,
+                                        device=dev, periodic_dims=(0,))
+    sem_b = StokesSEM.create(part.premesh, bcs, order, device=dev,
+                             neighbor_plan=part.plan)
+    assert sem_b.is_partitioned
+    u_b, p_b = run(sem_b)
+    # the same flow on the whole box, one rank
+    sem_g = StokesSEM.create(box_mesh((4, 2, 2), (0, 0, 0), (1, 1, 1),
+                                      periodic_dims=(0,)), bcs, order,
+                             device=dev)
+    u_g, p_g = run(sem_g)
+
+    def match(xl, xg):
+      """Index of the global point with the coordinates of each local one
+      (x taken modulo the period)."""
+      key = lambda x: torch.round(
+          torch.stack([x[:, 0] % 1.0, x[:, 1], x[:, 2]], 1) * 1e6).long()
+      kl, kg = key(xl), key(xg)
+      kl[:, 0] %= 10 ** 6
+      kg[:, 0] %= 10 ** 6
+      flat = lambda k: (k[:, 0] * 2000003 + k[:, 1]) * 2000003 + k[:, 2]
+      fg, order_g = torch.sort(flat(kg))
+      pos = torch.searchsorted(fg, flat(kl)).clamp(max=len(fg) - 1)
+      assert bool((fg[pos] == flat(kl)).all())
+      return order_g[pos]
+
+    iv = match(sem_b.velocity.mesh.node_coords, sem_g.velocity.mesh.node_coords)
+    ip = match(sem_b.pressure.pspace.mesh.node_coords,
+               sem_g.pressure.pspace.mesh.node_coords)
+    results[rank] = dict(
+        eu=float((u_b - u_g[iv]).abs().max() / u_g.abs().max()),
+        ep=float((p_b - p_g[ip]).abs().max() / p_g.abs().max()))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_navier_stokes_on_rank_local_blocks():
+  """StokesSEM built from each rank's own block premesh + the block builder's
+  neighbour plan (no global mesh anywhere) == the one-rank run on the whole
+  periodic box."""
+  world, port = 2, _free_port()
+  with mp.Manager() as mgr:
+    results = mgr.dict()
+    mp.spawn(_ns_blocks_worker, args=(world, port, 4, results), nprocs=world,
+             join=True)
+    res = dict(results)
+  assert sorted(res) == list(range(world))
+  for r in range(world):
+    assert res[r]['eu'] < 1e-8 and res[r]['ep'] < 1e-7, res[r]
