@@ -48,6 +48,20 @@ class BlockPartition:
     return comm.all_reduce_sum_(t)
 
 
+_SETUP_GROUP = {}
+
+
+def _setup_group():
+  """A gloo process group over all ranks for setup-time collectives (created
+  once; every rank must reach this call)."""
+  dist = comm.dist
+  if dist.get_backend() == 'gloo':
+    return None
+  if 'group' not in _SETUP_GROUP:
+    _SETUP_GROUP['group'] = dist.new_group(backend='gloo')
+  return _SETUP_GROUP['group']
+
+
 def tiled_element_order(n, ndim: int, tile: int) -> np.ndarray:
   """Permutation of the C-ordered elements of an `n[0] x .. x n[d-1]` block
   (`n` an int = cube) that visits them tile by tile (`tile^ndim` elements
@@ -155,8 +169,10 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
   neighbors, indices = [], []
   if periodic_dims:
     from swirl_fem_amd.distributed import discover
-    found = discover.discover_neighbors(
-        key, device=device if comm.dist.get_backend() == 'nccl' else 'cpu')
+    # setup-time routing of a few integers per surface node: always over a
+    # host (gloo) group, whatever backend carries the solver's traffic
+    found = discover.discover_neighbors(key, group=_setup_group(),
+                                        device='cpu')
     neighbors, indices = list(found.neighbors), list(found.indices)
   for off in itertools.product((-1, 0, 1), repeat=ndim):
     if periodic_dims:
