@@ -241,3 +241,22 @@ def test_periodic_block_partitions(grid, per, n, P):
     assert has_boundary == (len(per) < len(grid))
   if grid == (2, 1, 1):
     assert res[0][3] == [1] and res[1][3] == [0]  # one neighbour, met twice
+
+
+def test_block_plans_of_the_8_gpu_grid_are_symmetric():
+  """The 2 x 2 x 2 block grid of `bench.py --gpus 8` (no process group needed:
+  the non-periodic plans are built without communication): every pair of
+  ranks lists the same global nodes in the same order."""
+  grid = (2, 2, 2)
+  parts = [blocks.build_block_partition(3, 4, grid, r, device='cpu')
+           for r in range(8)]
+  for r, p in enumerate(parts):
+    assert p.plan.neighbors == [q for q in range(8) if q != r]
+    assert p.mesh.axis_name == 'blocks'
+    for q, ix in zip(p.plan.neighbors, p.plan.indices):
+      j = parts[q].plan.neighbors.index(r)
+      np.testing.assert_array_equal(
+          p.global_keys[ix], parts[q].global_keys[parts[q].plan.indices[j]])
+  # every global node is held by someone; holders of interior nodes are unique
+  allk = np.concatenate([p.global_keys for p in parts])
+  assert len(np.unique(allk)) == parts[0].num_global_nodes
