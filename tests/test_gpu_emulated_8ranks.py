@@ -45,14 +45,10 @@ class Mailbox:
     return t
 
 
-def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
+def _install_transport(monkeypatch, mail):
+  """Routes the product's communication calls through the mailbox."""
   from swirl_fem_amd import _ops
-  from swirl_fem_amd.core.fespace import FiniteElementSpace
-  from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
-  from swirl_fem_amd.distributed import blocks, comm, solver
-  from swirl_fem_amd.linalg.cg import cg
-  n, P, grid = 2, 4, (2, 2, 2)
-  mail = Mailbox(WORLD)
+  from swirl_fem_amd.distributed import comm, discover
 
   def exchange_buffers(plan, send_bufs, group=None, recv_bufs=None):
     got = mail.exchange(plan, send_bufs)
@@ -70,10 +66,63 @@ def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
                      recv_bufs=list(torch.split(recv, sizes)))
     return (recv, cat, [], send)
 
+  def discover_neighbors(global_keys, group=None, device='cpu'):
+    me = mail.local.rank
+    mail.box[('keys', me)] = np.asarray(global_keys)
+    mail.barrier.wait()
+    mine = mail.box[('keys', me)]
+    neighbors, indices = [], []
+    for q in range(WORLD):
+      if q == me:
+        continue
+      common, pos, _ = np.intersect1d(mine, mail.box[('keys', q)],
+                                      return_indices=True)
+      if len(common):
+        neighbors.append(q)
+        indices.append(pos.astype(np.int32))      # sorted by key
+    mail.barrier.wait()
+    return comm.NeighborPlan(rank=me, neighbors=neighbors, indices=indices)
+
   monkeypatch.setattr(comm, 'exchange_buffers', exchange_buffers)
   monkeypatch.setattr(comm, 'neighbor_exchange_start', start)
   monkeypatch.setattr(comm, 'all_reduce_sum_',
                       lambda t, group=None: mail.all_reduce(t))
+  monkeypatch.setattr(comm, 'get_rank', lambda: mail.local.rank)
+  monkeypatch.setattr(discover, 'discover_neighbors', discover_neighbors)
+  from swirl_fem_amd.distributed import blocks
+  monkeypatch.setattr(blocks, '_setup_group', lambda: None)
+
+
+def _run_ranks(mail, rank_main):
+  results, errors = {}, []
+
+  def body(rank):
+    try:
+      mail.local.rank = rank
+      results[rank] = rank_main(rank)
+    except Exception as e:            # pylint: disable=broad-except
+      import traceback
+      errors.append((rank, traceback.format_exc()))
+      mail.barrier.abort()
+
+  threads = [threading.Thread(target=body, args=(r,)) for r in range(WORLD)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=600)
+  assert not errors, errors[0][1]
+  assert sorted(results) == list(range(WORLD))
+  return results
+
+
+def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
+  from swirl_fem_amd.core.fespace import FiniteElementSpace
+  from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
+  from swirl_fem_amd.distributed import blocks, solver
+  from swirl_fem_amd.linalg.cg import cg
+  n, P, grid = 2, 4, (2, 2, 2)
+  mail = Mailbox(WORLD)
+  _install_transport(monkeypatch, mail)
 
   nodes = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
   quad = Quadrature1D.create_from_nodes_1d(nodes)
@@ -90,43 +139,80 @@ def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
                   tol=1e-12, maxiter=3000)
   lookup = dict(zip(whole.global_keys.tolist(), range(gm.num_nodes)))
 
-  results, errors = {}, []
-
   def rank_main(rank):
-    try:
-      mail.local.rank = rank
-      part = blocks.build_block_partition(n, P, grid, rank, device=DEV,
-                                          jitter=0.1)
-      mesh = part.mesh
-      bm = mesh.physical_masks.get('boundary')
-      if bm is None:
-        bm = torch.zeros(mesh.num_nodes, dtype=torch.bool, device=DEV)
-      fes = FiniteElementSpace.create(mesh, quad)
-      op = fes.helmholtz_operator(bm)
-      ids = torch.as_tensor([lookup[k] for k in part.global_keys.tolist()],
-                            device=DEV)
-      b_loc = fes.helmholtz_operator(None).apply(f[ids] * ~bm, 1.0, 0.0) * ~bm
-      A = solver.OverlappedHelmholtz(op, part.plan, 0.3, 1.0)
-      x, info = solver.cg(A, b_loc, part.plan, tol=1e-12, maxiter=3000)
-      holders = 1 + np.bincount(np.concatenate(part.plan.indices),
-                                minlength=mesh.num_nodes)
-      results[rank] = (float((x - xg[ids]).abs().max() / xg.abs().max()),
-                       info['num_iterations'], int(holders.max()),
-                       float(info['residual']))
-    except Exception as e:            # pylint: disable=broad-except
-      errors.append((rank, repr(e)))
-      mail.barrier.abort()
+    part = blocks.build_block_partition(n, P, grid, rank, device=DEV,
+                                        jitter=0.1)
+    mesh = part.mesh
+    bm = mesh.physical_masks.get('boundary')
+    if bm is None:
+      bm = torch.zeros(mesh.num_nodes, dtype=torch.bool, device=DEV)
+    fes = FiniteElementSpace.create(mesh, quad)
+    op = fes.helmholtz_operator(bm)
+    ids = torch.as_tensor([lookup[k] for k in part.global_keys.tolist()],
+                          device=DEV)
+    b_loc = fes.helmholtz_operator(None).apply(f[ids] * ~bm, 1.0, 0.0) * ~bm
+    A = solver.OverlappedHelmholtz(op, part.plan, 0.3, 1.0)
+    x, info = solver.cg(A, b_loc, part.plan, tol=1e-12, maxiter=3000)
+    holders = 1 + np.bincount(np.concatenate(part.plan.indices),
+                              minlength=mesh.num_nodes)
+    return (float((x - xg[ids]).abs().max() / xg.abs().max()),
+            info['num_iterations'], int(holders.max()),
+            float(info['residual']))
 
-  threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
-  for t in threads:
-    t.start()
-  for t in threads:
-    t.join(timeout=300)
-  assert not errors, errors
-  assert sorted(results) == list(range(WORLD))
+  results = _run_ranks(mail, rank_main)
   assert max(r[2] for r in results.values()) == 8      # the centre node
   for r in range(WORLD):
     assert results[r][0] < 1e-9, results[r]
     assert results[r][1] == results[0][1]
     assert results[r][3] == results[0][3]
   assert abs(results[0][1] - info_g['num_iterations']) <= 3
+
+
+def test_config4_taylor_green_on_2x2x2_periodic_blocks(monkeypatch):
+  """BASELINE config 4 in miniature: the triply periodic Taylor-Green box as
+  2 x 2 x 2 rank-local blocks (`taylor_green_blocks`: block premesh, periodic
+  lattice keys, neighbour discovery, partitioned StokesSEM with fused H, D,
+  D^T, E, C) against the one-rank periodic run."""
+  from swirl_fem_amd.examples import navier_stokes_driver as drv
+  n, order, steps = 2, 3, 2
+  mail = Mailbox(WORLD)
+  _install_transport(monkeypatch, mail)
+  kw = dict(order=order, reynolds=100.0, dt=1e-2, steps=steps, time_order=2,
+            device=DEV, tol=1e-11)
+  _, u_g, p_g, diag_g = drv.taylor_green(n=2 * n, **kw)
+  from swirl_fem_amd.navier_stokes.navier_stokes import StokesSEM
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  sem_g = StokesSEM.create(unit_cube_mesh(2 * n, ndim=3, a=0.0, b=2 * np.pi,
+                                          periodic_dims=(0, 1, 2)), {},
+                           order=order, device=DEV)
+  two_pi = 2 * np.pi
+
+  def keys(x):
+    k = torch.round((x % two_pi) / two_pi * 10 ** 6).long() % 10 ** 6
+    return (k[:, 0] * 1000003 + k[:, 1]) * 1000003 + k[:, 2]
+
+  def table(x, vals):
+    k, first = np.unique(keys(x).cpu().numpy(), return_index=True)
+    return k, vals[torch.as_tensor(first, device=DEV)]
+
+  kv, uv = table(sem_g.velocity.mesh.node_coords, u_g)
+  kp, pv = table(sem_g.pressure.pspace.mesh.node_coords, p_g)
+
+  def rank_main(rank):
+    sem, u, p, diag = drv.taylor_green_blocks(n=n, block_grid=(2, 2, 2),
+                                              rank=rank, **kw)
+    iu = torch.as_tensor(np.searchsorted(
+        kv, keys(sem.velocity.mesh.node_coords).cpu().numpy()), device=DEV)
+    ip = torch.as_tensor(np.searchsorted(
+        kp, keys(sem.pressure.pspace.mesh.node_coords).cpu().numpy()),
+        device=DEV)
+    return (float((u - uv[iu]).abs().max() / uv.abs().max()),
+            float((p - pv[ip]).abs().max() / pv.abs().max()),
+            diag['kinetic_energy'], diag['cg_iterations'])
+
+  results = _run_ranks(mail, rank_main)
+  for r in range(WORLD):
+    eu, ep, energy, iters = results[r]
+    assert eu < 1e-8 and ep < 1e-6, results[r][:2]
+    assert iters == results[0][3]
+    np.testing.assert_allclose(energy, diag_g['kinetic_energy'], rtol=1e-9)
