@@ -115,12 +115,18 @@ def _run_ranks(mail, rank_main):
   return results
 
 
-def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
+@pytest.mark.parametrize('n,P,dtype', [(2, 4, torch.float64),
+                                       (1, 12, torch.float32)])
+def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch, n, P, dtype):
+  """(1, 12, fp32) is BASELINE config 5 in miniature: p = 11 Helmholtz in
+  single precision on the 2 x 2 x 2 grid."""
   from swirl_fem_amd.core.fespace import FiniteElementSpace
   from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
   from swirl_fem_amd.distributed import blocks, solver
   from swirl_fem_amd.linalg.cg import cg
-  n, P, grid = 2, 4, (2, 2, 2)
+  grid = (2, 2, 2)
+  f64 = dtype == torch.float64
+  tol = 1e-12 if f64 else 1e-6
   mail = Mailbox(WORLD)
   _install_transport(monkeypatch, mail)
 
@@ -128,7 +134,7 @@ def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
   quad = Quadrature1D.create_from_nodes_1d(nodes)
   # one-rank solve of the whole box
   whole = blocks.build_block_partition(2 * n, P, (1, 1, 1), 0, device=DEV,
-                                       jitter=0.1)
+                                       jitter=0.1, dtype=dtype)
   gm = whole.mesh
   gop = FiniteElementSpace.create(gm, quad).helmholtz_operator(
       gm.physical_masks['boundary'])
@@ -136,12 +142,12 @@ def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
   f = torch.sin(3 * gx[:, 0]) * torch.cos(2 * gx[:, 1]) + gx[:, 2] ** 2
   xg, info_g = cg(gop.linear_operator(0.3, 1.0),
                   gop.apply(f * ~gm.physical_masks['boundary'], 1.0, 0.0),
-                  tol=1e-12, maxiter=3000)
+                  tol=tol, maxiter=3000)
   lookup = dict(zip(whole.global_keys.tolist(), range(gm.num_nodes)))
 
   def rank_main(rank):
     part = blocks.build_block_partition(n, P, grid, rank, device=DEV,
-                                        jitter=0.1)
+                                        jitter=0.1, dtype=dtype)
     mesh = part.mesh
     bm = mesh.physical_masks.get('boundary')
     if bm is None:
@@ -152,7 +158,7 @@ def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
                           device=DEV)
     b_loc = fes.helmholtz_operator(None).apply(f[ids] * ~bm, 1.0, 0.0) * ~bm
     A = solver.OverlappedHelmholtz(op, part.plan, 0.3, 1.0)
-    x, info = solver.cg(A, b_loc, part.plan, tol=1e-12, maxiter=3000)
+    x, info = solver.cg(A, b_loc, part.plan, tol=tol, maxiter=3000)
     holders = 1 + np.bincount(np.concatenate(part.plan.indices),
                               minlength=mesh.num_nodes)
     return (float((x - xg[ids]).abs().max() / xg.abs().max()),
@@ -162,10 +168,10 @@ def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch):
   results = _run_ranks(mail, rank_main)
   assert max(r[2] for r in results.values()) == 8      # the centre node
   for r in range(WORLD):
-    assert results[r][0] < 1e-9, results[r]
+    assert results[r][0] < (1e-9 if f64 else 2e-4), results[r]
     assert results[r][1] == results[0][1]
     assert results[r][3] == results[0][3]
-  assert abs(results[0][1] - info_g['num_iterations']) <= 3
+  assert abs(results[0][1] - info_g['num_iterations']) <= (3 if f64 else 10)
 
 
 def test_config4_taylor_green_on_2x2x2_periodic_blocks(monkeypatch):
