@@ -207,3 +207,67 @@ def test_taylor_green_3d_periodic():
   assert relerr(sem.filter(dev(w)), orc.filter(w)) < 1e-11
   assert relerr(sem.velocity.exchange(dev(w)), orc.vexchange(w)) < 1e-13
   assert relerr(sem.E(dev(q), 1e-2, 3), orc.E(q, 1e-2, 3)) < 1e-9
+
+
+def test_config3_unstructured_fixture():
+  """BASELINE config 3 in miniature: 4 x 4 quads, vertices
+  jittered by +-0.2 h, random element order and random local orientations,
+  p = 5 velocity / P-2 pressure, over-integration q = 8, Dirichlet walls with a
+  moving lid through `u_boundary`: every operator and one full step against the
+  oracle.  Only the four proper rotations are drawn here: a reflected element
+  has det J < 0 (the reference keeps the sign, core/fespace.py:346), so the
+  lumped mass of a node between a reflected and an unreflected element
+  cancels and B^-1 -- hence E and the step -- is undefined for the reference
+  too.  Reflections are covered at operator level in test_gpu_stokes_fused.py."""
+  import itertools
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  order, n = 5, 4
+  rng = np.random.default_rng(2)
+  pm = unit_cube_mesh(n, ndim=2)
+  x = pm.node_coords.copy()
+  inner = (x > 1e-9).all(1) & (x < 1 - 1e-9).all(1)
+  x[inner] += 0.2 / n * rng.uniform(-1, 1, (int(inner.sum()), 2))
+  rng3 = np.random.default_rng(3)
+  orients = [(perm, axes) for perm in itertools.permutations(range(2))
+             for r in range(3) for axes in itertools.combinations(range(2), r)
+             if (int(perm != (0, 1)) + len(axes)) % 2 == 0]
+  assert len(orients) == 4
+  el = []
+  for e in pm.elements[rng3.permutation(pm.num_elements)]:
+    perm, axes = orients[rng3.integers(len(orients))]
+    el.append(np.flip(e.reshape(2, 2).transpose(perm), axes).reshape(-1))
+  pm = pm.replace(node_coords=x, elements=np.array(el, dtype=np.int32))
+  bcs = {'boundary': (BCType.DIRICHLET, 0.0)}
+  sem = StokesSEM.create(pm, bcs, order=order, device=DEV)
+  assert sem._divgrad() is not None and sem._masked_operator() is not None
+  v, p = SC.staged_meshes(pm, order)
+  orc = O.StokesOracle(v, p, order, v['physical_masks']['boundary'])
+  assert (orc.vs.jacdets > 0).all()
+  nv, npr = len(v['node_coords']), len(p['node_coords'])
+  u = rng.standard_normal((nv, 2))
+  pr = rng.standard_normal(npr)
+  ud, pd = dev(u), dev(pr)
+  assert relerr(sem.A(ud), orc.A(u)) < 1e-10
+  assert relerr(sem.C(ud), orc.C(u)) < 1e-10
+  assert relerr(sem.D(ud), orc.D(u)) < 1e-10
+  assert relerr(sem.Dt(pd), orc.Dt(pr)) < 1e-10
+  assert relerr(sem.E(pd, DT, 2), orc.E(pr, DT, 2)) < 1e-9
+  assert relerr(sem.H(ud, 3.0, 0.01), 3.0 * orc.B(u) + 0.01 * orc.A(u)) < 1e-10
+  assert relerr(sem.filter(ud, 0.05), orc.filter(u, 0.05)) < 1e-11
+  # one Stokes step with the regularised lid as boundary velocity
+  xc = v['node_coords']
+  lid = (xc[:, 1] > 1 - 1e-12).astype(np.float64)
+  ub = np.stack([lid * 16 * xc[:, 0] ** 2 * (1 - xc[:, 0]) ** 2,
+                 np.zeros(nv)], axis=-1)
+  # a load vector lives on the free nodes only (rows of Dirichlet nodes are
+  # removed from the system; a load there could never be balanced)
+  f = 0.1 * rng.standard_normal((nv, 2)) * orc.interior
+  us, ps = [ub, ub], [np.zeros(npr), np.zeros(npr)]
+  ug, pg, _ = sem.stokes_one_step([dev(a) for a in us], [dev(a) for a in ps],
+                                  f=dev(f), mu=0.01, dt=1e-3, time_order=2,
+                                  u_boundary=dev(ub), tol=1e-10, atol=0.0)
+  uo, po, _ = orc.stokes_one_step(us, ps, f, 0.01, 1e-3, 2, alpha=0.05,
+                                  u_boundary=ub, tol=1e-10, atol=0.0)
+  assert np.isfinite(uo).all() and np.abs(uo).max() < 10
+  assert relerr(ug, uo) < 1e-8
+  assert np.abs(pg.cpu().numpy() - po).max() < 1e-6 * max(1.0, np.abs(po).max())
