@@ -133,17 +133,10 @@ def exchange_buffers(plan: NeighborPlan, send_bufs, group=None,
 
 def neighbor_exchange(u: torch.Tensor, plan: NeighborPlan,
                       group=None) -> torch.Tensor:
-  """QQ^T u for this rank's partition, as a new tensor (`sfem_pack` per
-  neighbour -> grouped send/recv -> `sfem_unpack_add`).  Device tensors only:
-  the pack / unpack halves are HIP kernels and nothing else."""
-  from swirl_fem_amd import _ops
-  idx = plan.device_indices(u.device)
-  send = [_ops.pack(u, ix) for ix in idx]
-  recv = exchange_buffers(plan, send, group=group)
-  out = u.clone()
-  for rb, ix in zip(recv, idx):
-    _ops.unpack_add(rb, ix, out)
-  return out
+  """QQ^T u for this rank's partition, as a new tensor (same memory layout as
+  `u`).  Device tensors only: the pack / unpack halves are HIP kernels and
+  nothing else."""
+  return neighbor_exchange_(u.clone(), plan, group)
 
 
 def neighbor_exchange_(u: torch.Tensor, plan: NeighborPlan,

@@ -239,7 +239,7 @@ class StokesVelocity:
     from swirl_fem_amd.distributed import comm
     if inplace:
       return comm.neighbor_exchange_(u, mesh.neighbor_plan)
-    return comm.neighbor_exchange(u.contiguous(), mesh.neighbor_plan)
+    return comm.neighbor_exchange(u, mesh.neighbor_plan)
 
   def _fused(self):
     """Fused operator without mask, or None if the space is not eligible."""
