@@ -893,3 +893,38 @@ def test_config2_properties_full_size(n):
     e = run.x - xs
     errs.append(float(torch.dot(e, op_d.apply(e))))
   assert all(b < a for a, b in zip(errs, errs[1:])), errs
+
+
+@pytest.mark.parametrize('n', [int(os.environ.get('SFEM_TEST_P11_N', '32'))])
+def test_config5_properties_at_scale(n):
+  """p = 11 fp32 Helmholtz on an n^3 block (config 5's per-GPU block is 64^3:
+  SFEM_TEST_P11_N=64): symmetry, constants in the nullspace of the stiffness
+  part, on-the-fly geometry == stored factors, fused p.Ap, within the fp32
+  tolerance of the north star (1e-5 relative, scaled by the operator norm)."""
+  from swirl_fem_amd import _lib
+  from swirl_fem_amd.distributed import blocks
+  P = 12
+  part = blocks.build_block_partition(n, P, (1, 1, 1), 0, device=DEV,
+                                      dtype=torch.float32)
+  mesh = part.mesh
+  grid = Nodes1D.create(P, NT['gll'])
+  fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
+  op = fes.helmholtz_operator(None)
+  g = torch.Generator(device=DEV).manual_seed(5)
+  u = torch.randn(mesh.num_nodes, dtype=torch.float32, device=DEV, generator=g)
+  v = torch.randn(mesh.num_nodes, dtype=torch.float32, device=DEV, generator=g)
+  Hu, Hv = op.apply(u, 0.5, 1.0), op.apply(v, 0.5, 1.0)
+  scale = float(Hu.abs().max())
+  a, b = float(torch.dot(Hu.double(), v.double())), float(
+      torch.dot(u.double(), Hv.double()))
+  assert abs(a - b) < 1e-5 * float(Hu.double().norm() * v.double().norm())
+  ones = torch.ones_like(u)
+  assert float(op.apply(ones, 0.0, 1.0).abs().max()) < 2e-5 * scale
+  # stored factors come from fp32 coordinate differences over elements of
+  # width 1/n: their own rounding (eps |x| / h) is what separates the two paths
+  op_s = fes.helmholtz_operator(None, 'stored')
+  assert float((op_s.apply(u, 0.5, 1.0) - Hu).abs().max()) < 2e-5 * n * scale
+  parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64, device=DEV)
+  op.apply(u, 0.5, 1.0, dot_out=parts)
+  ref = float(torch.dot(u.double(), Hu.double()))
+  assert abs(float(parts.sum()) - ref) < 1e-5 * abs(ref)
