@@ -121,9 +121,9 @@ def main():
                        'a fixed --elems^3 mesh split over the GPUs (blocks of '
                        'elems/px x elems/py x elems/pz elements)')
   ap.add_argument('--periodic', action='store_true',
-                  help='N>1: the box is periodic in every direction that is '
-                       'split over GPUs (N=8: the triply periodic 2x2x2 box of '
-                       'BASELINE config 4); a fully periodic run solves the '
+                  help='N>1: the triply periodic box of BASELINE config 4 '
+                       '(N=8: 2x2x2 blocks; along a direction with one block '
+                       'the images are summed on the rank itself); solves the '
                        'Helmholtz problem B + A instead of the singular A')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help="'gloo' rehearses the N>1 path with all ranks on the "
@@ -178,8 +178,7 @@ def main():
     block_n = tuple(args.n // g for g in grid_b)
   else:
     block_n = args.n
-  periodic_dims = tuple(d for d, g in enumerate(grid_b) if g >= 2) if (
-      args.periodic and world > 1) else ()
+  periodic_dims = (0, 1, 2) if args.periodic and world > 1 else ()
   if len(periodic_dims) == 3 and args.mass_coeff == 0.0:
     args.mass_coeff = 1.0          # no Dirichlet boundary left: A is singular
   part = blocks.build_block_partition(block_n, P, grid_b, rank,

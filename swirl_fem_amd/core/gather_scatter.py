@@ -69,12 +69,14 @@ def exchange(u, gather_indices, unique_indices=None, axis_name=None, *,
       # Every participating DOF is its own class: QQ^T is the identity.
       return u.clone()
     return _ops.exchange_local(u, gather_indices, unique_indices)
-  if unique_indices is not None:
-    raise NotImplementedError(
-        'intra-partition periodicity combined with partitioning')
   from swirl_fem_amd.distributed import comm
   if plan is None:
     raise ValueError('a partitioned exchange needs the rank\'s NeighborPlan')
+  if unique_indices is not None and not plan.has_local_images:
+    # the reference stops here too (core/gather_scatter.py:352-353); the block
+    # builder's plans carry the local images themselves
+    raise NotImplementedError(
+        'intra-partition periodicity combined with partitioning')
   return comm.neighbor_exchange(u, plan)
 
 

@@ -104,15 +104,13 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
   if len(ns) != ndim:
     raise ValueError(f'n has {len(ns)} entries for a {ndim}-d block grid')
   periodic_dims = tuple(int(d) for d in periodic_dims)
-  for d in periodic_dims:
-    if block_grid[d] < 2:
-      raise NotImplementedError(
-          f'periodic direction {d} needs at least 2 blocks (a rank would hold '
-          'both images of its boundary nodes)')
+  # directions with a single block: both images of a boundary node live on
+  # this rank (local periodic links, summed before / copied after the exchange)
+  self_periodic = tuple(d for d in periodic_dims if block_grid[d] == 1)
   if jitter and periodic_dims:
     raise NotImplementedError('jitter on a periodic box')
   coords_b = tuple(int(c) for c in np.unravel_index(rank, block_grid))
-  pm = box_mesh(ns, (0.0,) * ndim, (1.0,) * ndim)
+  pm = box_mesh(ns, (0.0,) * ndim, (1.0,) * ndim, periodic_dims=self_periodic)
   # affine map of the unit block into its slot of the global box
   x = np.array(pm.node_coords)
   for d in range(ndim):
@@ -125,9 +123,12 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
     x = x + jitter * h * s[:, None] * np.cos(
         2 * np.pi * x[:, ::-1] / (hi - lo))
   # keep only the faces that lie on the global boundary (the group lists, per
-  # axis, the FIRST side then the LAST side)
-  bfaces, at, keep = pm.physical_groups['boundary'], 0, []
+  # axis, the FIRST side then the LAST side; box_mesh turns the two sides of a
+  # self-periodic axis into links instead)
+  bfaces, at, keep = pm.physical_groups.get('boundary'), 0, []
   for d in range(ndim):
+    if d in self_periodic:
+      continue
     nf = int(np.prod([ns[a] for a in range(ndim) if a != d]))
     first, last = bfaces[at:at + nf], bfaces[at + nf:at + 2 * nf]
     at += 2 * nf
@@ -167,12 +168,24 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
   key = np.ravel_multi_index(tuple(glob[:, d] for d in range(ndim)), gdims)
 
   neighbors, indices = [], []
-  if periodic_dims:
+  arrays = rp.finalize_all()
+  local = {}
+  if self_periodic:
+    # class representative (smallest position) of every node, images of it
+    ni = np.asarray(arrays['node_indices']).astype(np.int64)
+    gi = np.asarray(arrays['exchange_gather_indices']).astype(np.int32)
+    local = dict(local_gather=gi,
+                 local_unique=np.asarray(arrays['exchange_unique_indices']),
+                 local_rep=ni[gi].astype(np.int32))
+    is_rep = ni == np.arange(len(ni))
+  if periodic_dims and int(np.prod(block_grid)) > 1:
     from swirl_fem_amd.distributed import discover
     # setup-time routing of a few integers per surface node: always over a
-    # host (gloo) group, whatever backend carries the solver's traffic
-    found = discover.discover_neighbors(key, group=_setup_group(),
-                                        device='cpu')
+    # host (gloo) group, whatever backend carries the solver's traffic.  Only
+    # class representatives take part (one image of a node per rank).
+    found = discover.discover_neighbors(
+        np.where(is_rep, key, -1) if self_periodic else key,
+        group=_setup_group(), device='cpu')
     neighbors, indices = list(found.neighbors), list(found.indices)
   for off in itertools.product((-1, 0, 1), repeat=ndim):
     if periodic_dims:
@@ -196,9 +209,8 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
   assert len(set(neighbors)) == len(neighbors)
   order = np.argsort(neighbors)
   plan = comm.NeighborPlan(rank=rank, neighbors=[neighbors[i] for i in order],
-                           indices=[indices[i] for i in order])
+                           indices=[indices[i] for i in order], **local)
 
-  arrays = rp.finalize_all()
   world = int(np.prod(block_grid))
   mesh = Mesh.create(
       gridpoints_1d=rp.gridpoints_1d, device=device, dtype=dtype,
@@ -207,8 +219,12 @@ def build_block_partition(n, P: int, block_grid, rank: int, *,
           k: v for k, v in arrays.items()
           if k in ('node_coords', 'elements', 'node_indices', 'physical_masks')
       },
-      exchange_gather_indices=(np.concatenate(indices).astype(np.int32)
-                               if world > 1 and indices else None))
+      exchange_gather_indices=(
+          arrays['exchange_gather_indices'] if self_periodic else
+          np.concatenate(indices).astype(np.int32)
+          if world > 1 and indices else None),
+      exchange_unique_indices=(arrays['exchange_unique_indices']
+                               if self_periodic else None))
   return BlockPartition(mesh=mesh, rank=rank, block_grid=block_grid,
                         block_coords=coords_b,
                         num_global_nodes=int(np.prod(gdims)), plan=plan,

@@ -26,6 +26,11 @@ import torch
 import torch.distributed as dist
 
 
+# Set by tests that replace `exchange_buffers` with an in-process transport:
+# the split exchange then goes through it instead of posting P2P operations.
+_BLOCKING_TRANSPORT = False
+
+
 def get_rank() -> int:
   if dist.is_available() and dist.is_initialized():
     return dist.get_rank()
@@ -49,7 +54,31 @@ class NeighborPlan:
   rank: int
   neighbors: list
   indices: list
+  # Periodic images held by this rank itself (a box that is periodic in a
+  # direction with a single block): `local_gather[i]` is the position of an
+  # image node, `local_unique[i]` its class and `local_rep[i]` the position of
+  # the class representative.  Only representatives appear in `indices`.
+  local_gather: np.ndarray | None = None
+  local_unique: np.ndarray | None = None
+  local_rep: np.ndarray | None = None
   _dev: dict = dataclasses.field(default_factory=dict, repr=False)
+
+  @property
+  def has_local_images(self) -> bool:
+    return self.local_gather is not None and len(self.local_gather) > 0
+
+  def local_device(self, device):
+    """(gather int32, unique host array, gather int64, rep int64) on device."""
+    key = ('local', str(device))
+    if key not in self._dev:
+      g = np.ascontiguousarray(self.local_gather, dtype=np.int32)
+      self._dev[key] = (
+          torch.as_tensor(g, dtype=torch.int32, device=device),
+          np.ascontiguousarray(self.local_unique, dtype=np.int32),
+          torch.as_tensor(g, dtype=torch.int64, device=device),
+          torch.as_tensor(np.asarray(self.local_rep), dtype=torch.int64,
+                          device=device))
+    return self._dev[key]
 
   @classmethod
   def from_gather_indices(cls, gather_indices: np.ndarray,
@@ -88,19 +117,44 @@ class NeighborPlan:
                         [len(ix) for ix in self.indices])
     return self._dev[key]
 
-  def interface_weights(self, device):
-    """`(idx, w)`: the interface nodes of this partition (each once, int64) and
-    `w = 1 - 1/m`, m = number of partitions holding the node.  For vectors that
+  def interface_weights(self, device, num_nodes=None, group=None):
+    """`(idx, w)`: the nodes of this partition that have other holders (each
+    once, int64) and `w = 1 - 1/m`, m = number of holders (other ranks and,
+    with local periodic images, other images on this rank).  For vectors that
     are *consistent* (equal on all holders)  sum_ranks (a.b - sum_idx w a b)
     is the inner product over the unique global nodes."""
     key = ('w', str(device))
     if key not in self._dev:
-      cat = (np.concatenate(self.indices) if self.indices
-             else np.zeros(0, np.int32))
-      idx, cnt = np.unique(cat[cat >= 0], return_counts=True)
-      w = 1.0 - 1.0 / (1.0 + cnt)
-      self._dev[key] = (torch.as_tensor(idx, dtype=torch.int64, device=device),
-                        torch.as_tensor(w, dtype=torch.float64, device=device))
+      if self.has_local_images:
+        # count the holders by exchanging ones (a collective call)
+        if num_nodes is None:
+          raise ValueError('interface_weights: num_nodes needed with local '
+                           'periodic images')
+        m = neighbor_exchange_(torch.ones(num_nodes, dtype=torch.float64,
+                                          device=device), self, group)
+        idx = torch.nonzero(m > 1.5).reshape(-1)
+        self._dev[key] = (idx, 1.0 - 1.0 / m[idx])
+      else:
+        cat = (np.concatenate(self.indices) if self.indices
+               else np.zeros(0, np.int32))
+        idx, cnt = np.unique(cat[cat >= 0], return_counts=True)
+        w = 1.0 - 1.0 / (1.0 + cnt)
+        self._dev[key] = (
+            torch.as_tensor(idx, dtype=torch.int64, device=device),
+            torch.as_tensor(w, dtype=torch.float64, device=device))
+    return self._dev[key]
+
+  def interface_nodes(self, device) -> torch.Tensor:
+    """Positions (int64, unique) of every node that takes part in the exchange:
+    nodes shared with other ranks and local periodic images."""
+    key = ('iface', str(device))
+    if key not in self._dev:
+      parts = [np.asarray(ix) for ix in self.indices]
+      if self.has_local_images:
+        parts += [np.asarray(self.local_gather), np.asarray(self.local_rep)]
+      cat = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+      self._dev[key] = torch.as_tensor(np.unique(cat[cat >= 0]),
+                                       dtype=torch.int64, device=device)
     return self._dev[key]
 
 
@@ -139,20 +193,29 @@ def neighbor_exchange(u: torch.Tensor, plan: NeighborPlan,
   return neighbor_exchange_(u.clone(), plan, group)
 
 
+def _local_sum_(u, plan):
+  """Step 1 with local periodic images: every image gets its class sum."""
+  from swirl_fem_amd import _ops
+  gi, ui, _, _ = plan.local_device(u.device)
+  _ops.exchange_local(u, gi, ui, inplace=True)
+
+
+def _local_broadcast_(u, plan):
+  """Step 3: the representative's (now global) value goes to all images."""
+  _, _, g64, rep = plan.local_device(u.device)
+  u[g64] = u[rep]
+
+
 def neighbor_exchange_(u: torch.Tensor, plan: NeighborPlan,
                        group=None) -> torch.Tensor:
   """In-place QQ^T on the interface nodes: one pack launch for all neighbours,
   one grouped send/recv, one atomic unpack-add.  `u` may be (N,), (N, nc)
-  row-major or component-major; interior nodes are not touched (no clone)."""
-  from swirl_fem_amd import _ops
-  if not plan.neighbors:
-    return u
-  cat, sizes = plan.concat_indices(u.device)
-  send = _ops.pack_strided(u, cat)
-  recv = torch.empty_like(send)
-  exchange_buffers(plan, list(torch.split(send, sizes)), group=group,
-                   recv_bufs=list(torch.split(recv, sizes)))
-  return _ops.unpack_add_atomic(recv, cat, u)
+  row-major or component-major; interior nodes are not touched (no clone).
+
+  With local periodic images (see `NeighborPlan`): sum the images on this
+  rank, exchange the class representatives with the other ranks, copy the
+  result back to every image."""
+  return neighbor_exchange_finish(neighbor_exchange_start(u, plan, group), u)
 
 
 def neighbor_exchange_start(u: torch.Tensor, plan: NeighborPlan, group=None):
@@ -162,31 +225,36 @@ def neighbor_exchange_start(u: torch.Tensor, plan: NeighborPlan, group=None):
   interior elements of an operator) overlap with them.  `u` must not change at
   the interface nodes in between."""
   from swirl_fem_amd import _ops
+  if plan.has_local_images:
+    _local_sum_(u, plan)
   if not plan.neighbors:
-    return None
+    return (None, None, [], None, plan)
   cat, sizes = plan.concat_indices(u.device)
   send = _ops.pack_strided(u, cat)
   recv = torch.empty_like(send)
   sends, recvs = list(torch.split(send, sizes)), list(torch.split(recv, sizes))
-  if send.is_cuda and dist.get_backend(group) == 'gloo':
+  if _BLOCKING_TRANSPORT or (send.is_cuda and
+                             dist.get_backend(group) == 'gloo'):
     exchange_buffers(plan, sends, group=group, recv_bufs=recvs)   # blocking
-    return (recv, cat, [], send)
+    return (recv, cat, [], send, plan)
   ops = []
   for q, sb, rb in zip(plan.neighbors, sends, recvs):
     ops.append(dist.P2POp(dist.isend, sb, q, group=group))
     ops.append(dist.P2POp(dist.irecv, rb, q, group=group))
-  return (recv, cat, dist.batch_isend_irecv(ops), send)
+  return (recv, cat, dist.batch_isend_irecv(ops), send, plan)
 
 
 def neighbor_exchange_finish(handle, u: torch.Tensor) -> torch.Tensor:
   """Second half: waits for the transfers and adds the neighbours' values."""
   from swirl_fem_amd import _ops
-  if handle is None:
-    return u
-  recv, cat, reqs, _send = handle
+  recv, cat, reqs, _send, plan = handle
   for req in reqs:
     req.wait()
-  return _ops.unpack_add_atomic(recv, cat, u)
+  if recv is not None:
+    _ops.unpack_add_atomic(recv, cat, u)
+  if plan.has_local_images:
+    _local_broadcast_(u, plan)
+  return u
 
 
 def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -57,10 +57,9 @@ class OverlappedHelmholtz:
   def __init__(self, op, plan: comm.NeighborPlan, lambda0=0.0, lambda1=1.0,
                group=None):
     mesh = op.fespace.mesh
-    idx, _ = plan.interface_weights(op.enc.device)
     on_iface = torch.zeros(mesh.num_nodes + 1, dtype=torch.bool,
                            device=op.enc.device)
-    on_iface[idx] = True
+    on_iface[plan.interface_nodes(op.enc.device)] = True
     boundary = on_iface[mesh.elements.to(torch.int64)].any(dim=1)  # -1 -> pad
     self.boundary_op, self.interior_op = op.split(boundary)
     self.plan, self.group = plan, group
@@ -99,7 +98,8 @@ def make_runner(local_op, b_local, plan: comm.NeighborPlan, *, x0=None,
   return cg_lib.CGRunner(
       A, b, x0, tol=tol, atol=atol,
       maxiter=maxiter, reduce_fn=reduce_fn,
-      interface=plan.interface_weights(b.device))
+      interface=plan.interface_weights(b.device, num_nodes=b.shape[0],
+                                       group=group))
 
 
 def cg(local_op, b_local, plan: comm.NeighborPlan, *, x0=None, tol=1e-5,

@@ -20,7 +20,7 @@ import time
 import numpy as np
 import torch
 
-from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+from swirl_fem_amd.common.premesh_commons import box_mesh, unit_cube_mesh
 from swirl_fem_amd.navier_stokes import navier_stokes
 from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
 
@@ -120,9 +120,11 @@ def lid_driven_cavity(n=8, order=5, reynolds=100.0, dt=1e-3, steps=10,
 
 def taylor_green(n=4, order=3, reynolds=100.0, dt=1e-2, steps=5, time_order=3,
                  device=None, tol=1e-8, profile=None):
-  """3D Taylor-Green vortex on the periodic box [0, 2 pi]^3."""
+  """3D Taylor-Green vortex on the periodic box [0, 2 pi]^3 (`n` elements
+  per direction, or one count per direction)."""
   timer = _StepTimer(profile, device)
-  pm = unit_cube_mesh(n, ndim=3, a=0.0, b=2 * np.pi, periodic_dims=(0, 1, 2))
+  ns = (n,) * 3 if np.isscalar(n) else tuple(n)
+  pm = box_mesh(ns, (0.0,) * 3, (2 * np.pi,) * 3, periodic_dims=(0, 1, 2))
   sem = StokesSEM.create(pm, {}, order=order, device=device)
   x = sem.velocity.mesh.node_coords
   u0 = torch.stack([torch.sin(x[:, 0]) * torch.cos(x[:, 1]) * torch.cos(x[:, 2]),

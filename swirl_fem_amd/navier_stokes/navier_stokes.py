@@ -172,12 +172,18 @@ class StokesVelocity:
       # `premesh` is this rank's own block (distributed/blocks.py): the
       # refined block mesh numbers its nodes exactly like the block builder's
       # mesh, so the builder's neighbour plan applies as it is
-      cat = (np.concatenate(neighbor_plan.indices).astype(np.int32)
-             if neighbor_plan.indices else np.zeros(0, np.int32))
-      vmesh = vmesh.replace(
-          axis_name='blocks', neighbor_plan=neighbor_plan,
-          exchange_gather_indices=torch.as_tensor(cat, device=vmesh.device),
-          exchange_unique_indices=None)
+      if neighbor_plan.has_local_images:
+        # periodic along a direction with a single block: the mesh keeps the
+        # gather / unique indices of its own images, which the plan sums
+        # before and copies back after the neighbour exchange
+        vmesh = vmesh.replace(axis_name='blocks', neighbor_plan=neighbor_plan)
+      else:
+        cat = (np.concatenate(neighbor_plan.indices).astype(np.int32)
+               if neighbor_plan.indices else np.zeros(0, np.int32))
+        vmesh = vmesh.replace(
+            axis_name='blocks', neighbor_plan=neighbor_plan,
+            exchange_gather_indices=torch.as_tensor(cat, device=vmesh.device),
+            exchange_unique_indices=None)
     vspace = FiniteElementSpace.create(
         mesh=vmesh, quadrature=Quadrature1D.create_from_nodes_1d(gridpoints_1d))
     interior_mask = dirichlet_bc(vmesh, boundary_conditions)

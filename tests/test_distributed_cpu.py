@@ -203,11 +203,27 @@ def _periodic_worker(rank, world, port, grid, per, n, P, results):
                                         periodic_dims=per)
     rng = np.random.default_rng(200 + rank)
     u = torch.from_numpy(rng.standard_normal(part.mesh.num_nodes))
-    idx = [torch.as_tensor(ix) for ix in part.plan.indices]
-    recv = comm.exchange_buffers(part.plan, [_oracle_pack(u, ix) for ix in idx])
+    plan = part.plan
     out = u.clone()
-    for rb, ix in zip(recv, idx):
+    if plan.has_local_images:           # 1. sum the images held by this rank
+      sums = np.zeros(int(plan.local_unique.max()) + 1)
+      np.add.at(sums, plan.local_unique, out.numpy()[plan.local_gather])
+      out.numpy()[plan.local_gather] = sums[plan.local_unique]
+    idx = [torch.as_tensor(ix) for ix in plan.indices]
+    recv = comm.exchange_buffers(plan, [_oracle_pack(out, ix) for ix in idx])
+    for rb, ix in zip(recv, idx):       # 2. representatives across ranks
       _oracle_unpack_add(rb, ix, out)
+    if plan.has_local_images:           # 3. back to every image
+      out.numpy()[plan.local_gather] = out.numpy()[plan.local_rep]
+    # the Dirichlet mask is exactly the faces of the non-periodic directions
+    x = part.mesh.node_coords.numpy()
+    on_wall = np.zeros(len(x), dtype=bool)
+    for d in range(len(grid)):
+      if d not in per:
+        on_wall |= (np.abs(x[:, d]) < 1e-12) | (np.abs(x[:, d] - 1.0) < 1e-12)
+    mask = part.mesh.physical_masks.get('boundary')
+    np.testing.assert_array_equal(
+        on_wall, np.zeros(len(x), bool) if mask is None else mask.numpy())
     has_boundary = 'boundary' in part.mesh.physical_masks
     results[rank] = (part.global_keys, u.numpy(), out.numpy(),
                      part.plan.neighbors, has_boundary, part.num_global_nodes)
@@ -217,7 +233,15 @@ def _periodic_worker(rank, world, port, grid, per, n, P, results):
 
 @pytest.mark.parametrize('grid,per,n,P', [((2, 1, 1), (0,), 2, 3),
                                           ((2, 2, 1), (0, 1), 2, 3),
-                                          ((2, 2), (0, 1), (2, 3), 4)])
+                                          ((2, 2), (0, 1), (2, 3), 4),
+                                          # single block along a periodic
+                                          # direction: local images as well
+                                          ((2, 1, 1), (0, 1, 2), 2, 3),
+                                          ((2, 1), (0, 1), 3, 4),
+                                          ((2, 2, 1), (0, 1, 2), 2, 3),
+                                          # ... next to a Dirichlet direction
+                                          ((2, 1), (1,), 3, 4),
+                                          ((1, 2, 1), (0, 1), 2, 3)])
 def test_periodic_block_partitions(grid, per, n, P):
   """Blocks of a box that is periodic across the partition cuts (config 4's
   situation): the neighbour plan comes from the router-based discovery on
@@ -230,8 +254,9 @@ def test_periodic_block_partitions(grid, per, n, P):
              nprocs=world, join=True)
     res = dict(results)
   tot = {}
+  self_periodic = any(grid[d] == 1 for d in per)
   for keys, u, _, _, _, _ in res.values():
-    assert len(np.unique(keys)) == len(keys)      # one image per rank
+    assert self_periodic or len(np.unique(keys)) == len(keys)
     for k, v in zip(keys.tolist(), u):
       tot[k] = tot.get(k, 0.0) + v
   assert len(tot) == res[0][5]                    # unique periodic nodes
