@@ -320,10 +320,11 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': '3D %s CG iteration, %d^3 hex elements %s, '
-                        'p=%d GLL collocated, %s, Dirichlet' % (
+                        'p=%d GLL collocated, %s, %s' % (
                             'Helmholtz' if args.mass_coeff else 'Laplacian',
                             args.n, 'per GPU' if args.scaling == 'weak'
-                            else 'in total', args.p, args.dtype),
+                            else 'in total', args.p, args.dtype,
+                            'triply periodic' if periodic_dims else 'Dirichlet'),
             'elements_per_gpu': E, 'dofs_global': N_global,
             'blocks': 'x'.join(map(str, block_grid(world))),
             'periodic_dims': list(periodic_dims),
