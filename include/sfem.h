@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFEM_ABI_VERSION 1
+#define SFEM_ABI_VERSION 2
 
 enum { SFEM_F32 = 0, SFEM_F64 = 1 };
 enum {
@@ -97,6 +97,23 @@ int sfem_exchange_local(const void* u, void* out, const int32_t* gidx,
                         const int32_t* unique, int64_t count,
                         int64_t num_nodes, void* sums, int64_t num_unique,
                         int ncomp, int dtype, sfem_stream_t stream);
+
+/* The same QQ^T in place and in ONE launch, from the classes themselves
+ * (CSR: class c holds the nodes members[offsets[c] .. offsets[c+1])):
+ * every member receives the sum over its class, summed in member order
+ * (reproducible, no workspace, no atomics).  `u[k * node_stride +
+ * c * comp_stride]` addresses node k, component c: (N, nc) row-major is
+ * (nc, 1), component-major strips are (1, N).                               */
+int sfem_exchange_classes(void* u, const int32_t* members,
+                          const int32_t* offsets, int64_t num_classes,
+                          int ncomp, int64_t node_stride, int64_t comp_stride,
+                          int dtype, sfem_stream_t stream);
+
+/* Clears `nstrips` strips of `strip_len` reals, `strip_stride` reals apart:
+ * the shared-node range of every component ahead of an atomically assembled
+ * apply (one launch for short strips, the runtime's fill for long ones).     */
+int sfem_zero_strips(void* base, int64_t strip_len, int64_t strip_stride,
+                     int nstrips, int dtype, sfem_stream_t stream);
 
 /* Partitioned QQ^T, the pack / unpack halves around the RCCL neighbour
  * exchange that replaces lax.psum (core/gather_scatter.py:247-248):
@@ -347,6 +364,13 @@ int sfem_dot_indexed(const void* a, const void* b, const int64_t* idx,
                      const double* w, int64_t count, int ncomp,
                      int64_t node_stride, int64_t comp_stride, double scale,
                      double* result, int dtype, sfem_stream_t stream);
+/* out = w - (b . w / total) 1: the nullspace projection of the pressure
+ * preconditioner (navier_stokes.py:73-78 with b = B 1, total = 1 . B 1).
+ * Two launches, no atomics; `partials`: SFEM_DOT_SLOTS device doubles of
+ * workspace (need not be cleared).  `out` may alias `w`.                     */
+int sfem_subtract_weighted_mean(const void* w, const void* b, double total,
+                                void* out, double* partials, int64_t count,
+                                int dtype, sfem_stream_t stream);
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
                     double atol, double* partials, sfem_stream_t stream);
 int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,

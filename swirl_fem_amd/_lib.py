@@ -12,7 +12,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsfem_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SFEM_F32, SFEM_F64 = 0, 1
 SFEM_CG_NSCALARS = 16
@@ -63,6 +63,11 @@ SIGNATURES = {
                          c_ptr],
     'sfem_exchange_local': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr,
                             c_i64, c_i32, c_i32, c_ptr],
+    'sfem_exchange_classes': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64,
+                              c_i32, c_ptr],
+    'sfem_zero_strips': [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr],
+    'sfem_subtract_weighted_mean': [c_ptr, c_ptr, c_dbl, c_ptr, c_ptr, c_i64,
+                                    c_i32, c_ptr],
     'sfem_pack': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     'sfem_unpack_add': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     'sfem_pack_strided': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64,

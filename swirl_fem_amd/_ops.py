@@ -126,46 +126,93 @@ def scatter_csr(u_local, offsets, slots, num_nodes, ncomp=1):
   return out
 
 
-_unique_cache = {}
+_class_cache = {}
+
+
+def _exchange_classes(gather_indices, unique_indices, dev):
+  """CSR of the periodic classes on `dev`: (members, offsets, num_classes).
+
+  `gather_indices[i]` is a participating node and `unique_indices[i]` its
+  class (core/gather_scatter.py:284-315); entries of -1 are padding.  Cached
+  per index pair (the arrays of a mesh are static)."""
+  key = (id(gather_indices), id(unique_indices), str(dev))
+  cached = _class_cache.get(key)
+  if (cached is not None and cached[0] is gather_indices and
+      cached[1] is unique_indices):
+    return cached[2:]
+  gi = (gather_indices.detach().cpu().numpy()
+        if isinstance(gather_indices, torch.Tensor)
+        else np.asarray(gather_indices)).astype(np.int64).reshape(-1)
+  ui = np.asarray(unique_indices).astype(np.int64).reshape(-1)
+  if gi.shape != ui.shape:
+    raise ValueError('gather and unique indices must have the same length')
+  keep = gi >= 0
+  gi, ui = gi[keep], ui[keep]
+  order = np.lexsort((gi, ui))                  # by class, then by node id
+  classes, counts = np.unique(ui, return_counts=True)
+  offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+  members = torch.as_tensor(gi[order].astype(np.int32), device=dev)
+  out = (members, torch.as_tensor(offsets, device=dev), len(classes))
+  if len(_class_cache) >= 64:                   # meshes come and go
+    _class_cache.pop(next(iter(_class_cache)))
+  _class_cache[key] = (gather_indices, unique_indices) + out
+  return out
 
 
 def exchange_local(u, gather_indices, unique_indices, inplace=False):
   """Unpartitioned QQ^T; `unique_indices` is a host array (static).
 
-  `inplace=True` overwrites `u` (only its periodic images change): no copy of
-  the field, which is most of the cost of this operation."""
-  gidx = _idx(gather_indices)
+  One launch for all components, in place on a copy of `u` (or on `u` itself
+  with `inplace=True`: only the periodic images change)."""
   cm = is_component_major(u)
   if not cm:
     u = u.contiguous()
-  dev = _dev(u.movedim(-1, 0) if cm else u, gidx)
-  key = (id(unique_indices), str(dev))
-  cached = _unique_cache.get(key)
-  if cached is None or cached[0] is not unique_indices:
-    uni = torch.as_tensor(np.ascontiguousarray(unique_indices),
-                          dtype=torch.int32, device=dev)
-    num_unique = int(unique_indices.max()) + 1 if len(unique_indices) else 0
-    _unique_cache[key] = cached = (unique_indices, uni, num_unique)
-  _, uni, num_unique = cached
-  lib = _lib.load()
-
-  def run(src, dst, ncomp):
-    sums = torch.empty((max(num_unique, 1), ncomp), dtype=u.dtype, device=dev)
-    _lib.check(lib.sfem_exchange_local(
-        _ptr(src), _ptr(dst), _ptr(gidx), _ptr(uni), gidx.numel(),
-        src.shape[0], _ptr(sums), num_unique, ncomp, _dtype_code(u),
-        _stream(dev)), 'sfem_exchange_local')
-
+  dev = _dev(u.movedim(-1, 0) if cm else u)
+  members, offsets, num_classes = _exchange_classes(gather_indices,
+                                                    unique_indices, dev)
+  out = u if inplace else u.clone()             # clone keeps the dense layout
+  ncomp, ns, cs = _node_view(out)
   with torch.cuda.device(dev):
-    if cm:
-      # every component is a contiguous strip: exchange each one in place
-      out = u if inplace else u.clone()       # clone keeps the dense layout
-      strips = out.movedim(-1, 0)
-      for k in range(strips.shape[0]):
-        run(strips[k], strips[k], 1)
-      return out
-    out = u if inplace else torch.empty_like(u)
-    run(u, out, 1 if u.dim() == 1 else u.shape[-1])
+    _lib.check(_lib.load().sfem_exchange_classes(
+        _ptr(out), _ptr(members), _ptr(offsets), num_classes, ncomp, ns, cs,
+        _dtype_code(out), _stream(dev)), 'sfem_exchange_classes')
+  return out
+
+
+def exchange_local_atomic(u, gather_indices, unique_indices):
+  """The same QQ^T through `sfem_exchange_local` (segment sums by atomics into
+  a workspace, then expansion): the C-ABI's out-of-place form."""
+  gidx = _idx(gather_indices)
+  u = u.contiguous()
+  dev = _dev(u, gidx)
+  uni = torch.as_tensor(np.ascontiguousarray(unique_indices),
+                        dtype=torch.int32, device=dev)
+  num_unique = int(np.max(unique_indices)) + 1 if len(unique_indices) else 0
+  ncomp = 1 if u.dim() == 1 else u.shape[-1]
+  sums = torch.empty((max(num_unique, 1), ncomp), dtype=u.dtype, device=dev)
+  out = torch.empty_like(u)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_exchange_local(
+        _ptr(u), _ptr(out), _ptr(gidx), _ptr(uni), gidx.numel(), u.shape[0],
+        _ptr(sums), num_unique, ncomp, _dtype_code(u), _stream(dev)),
+               'sfem_exchange_local')
+  return out
+
+
+def subtract_weighted_mean(w, b, total, partials, out=None):
+  """out = w - (b . w / total) 1 (two launches, no host synchronisation)."""
+  w, b = w.contiguous(), b.contiguous()
+  if w.shape != b.shape or w.dtype != b.dtype:
+    raise ValueError('subtract_weighted_mean: operands differ in shape / dtype')
+  if out is None:
+    out = torch.empty_like(w)
+  dev = _dev(w, b, out, partials)
+  if partials.dtype != torch.float64 or partials.numel() < _lib.SFEM_DOT_SLOTS:
+    raise ValueError('partials: SFEM_DOT_SLOTS float64 values')
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_subtract_weighted_mean(
+        _ptr(w), _ptr(b), float(total), _ptr(out), _ptr(partials), w.numel(),
+        _dtype_code(w), _stream(dev)), 'sfem_subtract_weighted_mean')
   return out
 
 

@@ -173,6 +173,54 @@ unpack_add_atomic_kernel(const T* __restrict__ buf,
   }
 }
 
+// QQ^T through the classes themselves: class c owns members[offsets[c] ..
+// offsets[c+1]); one thread sums them (in member order: reproducible) and
+// writes the sum back to each.  In place, no workspace, all components in
+// one launch; `u[k * node_stride + c * comp_stride]` covers (N, nc) row-major
+// and component-major fields alike.
+template <typename T>
+__global__ void __launch_bounds__(256)
+exchange_classes_kernel(T* __restrict__ u, const int32_t* __restrict__ members,
+                        const int32_t* __restrict__ offsets,
+                        int64_t num_classes, int ncomp, int64_t node_stride,
+                        int64_t comp_stride) {
+  const int64_t total = num_classes * ncomp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    int64_t cls;
+    int c;
+    if (comp_stride == 1) {          // interleaved: components adjacent
+      cls = t / ncomp;
+      c = (int)(t - cls * ncomp);
+    } else {                         // strips: classes adjacent
+      c = (int)(t / num_classes);
+      cls = t - (int64_t)c * num_classes;
+    }
+    const int32_t lo = offsets[cls], hi = offsets[cls + 1];
+    T sum = T(0);
+    for (int32_t m = lo; m < hi; ++m)
+      sum += u[(int64_t)members[m] * node_stride + c * comp_stride];
+    for (int32_t m = lo; m < hi; ++m)
+      u[(int64_t)members[m] * node_stride + c * comp_stride] = sum;
+  }
+}
+
+// Clears `nstrips` equally long strips of a field in one launch (the shared
+// node range of every component before an atomically assembled apply).
+template <typename T>
+__global__ void __launch_bounds__(256)
+zero_strips_kernel(T* __restrict__ base, int64_t strip_len,
+                   int64_t strip_stride, int nstrips) {
+  const int64_t total = strip_len * nstrips;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t s = t / strip_len;
+    base[s * strip_stride + (t - s * strip_len)] = T(0);
+  }
+}
+
 // ------------------------------------------------------------ CG kernels ---
 // Block-level sum of one double per thread; one atomic per workgroup.
 __device__ inline double block_sum(double v) {
@@ -234,6 +282,41 @@ dot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t count,
   }
   const double total = block_sum(acc);
   if (threadIdx.x == 0) unsafeAtomicAdd(result, total);
+}
+
+// out = w - (b . w / total) 1 in two launches without atomics or a cleared
+// accumulator: every workgroup of the first kernel stores its partial sum, every
+// workgroup of the second adds the (<= 1024) partials up again.
+template <typename T>
+__global__ void __launch_bounds__(512)
+dot_partials_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                    int64_t count, double* __restrict__ partials) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride)
+    acc += (double)a[i] * (double)b[i];
+  const double total = block_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+subtract_mean_kernel(const T* __restrict__ w, const double* __restrict__ partials,
+                     int num_partials, double inv_total, T* __restrict__ out,
+                     int64_t count) {
+  __shared__ double mean;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < num_partials; i += blockDim.x)
+    acc += partials[i];
+  const double total = block_sum(acc);
+  if (threadIdx.x == 0) mean = total * inv_total;
+  __syncthreads();
+  const T m = (T)mean;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride)
+    out[i] = w[i] - m;
 }
 
 // scalars (16 doubles): [0] gamma [1] p.Ap [2] gamma_new [3] alpha [4] beta
@@ -593,6 +676,74 @@ int sfem_exchange_local(const void* u, void* out, const int32_t* gidx,
     hipLaunchKernelGGL(exchange_expand_kernel<T>, dim3(grid), dim3(256), 0,
                        as_stream(stream), (const T*)sums, gidx, unique,
                        (T*)out, count, ncomp);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_exchange_classes(void* u, const int32_t* members,
+                          const int32_t* offsets, int64_t num_classes,
+                          int ncomp, int64_t node_stride, int64_t comp_stride,
+                          int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(num_classes >= 0 && ncomp >= 1 && node_stride >= 1 &&
+               comp_stride >= 1, "sfem_exchange_classes: bad sizes");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_exchange_classes: unknown dtype %d", dtype);
+  if (num_classes == 0) return SFEM_OK;
+  SFEM_REQUIRE(u && members && offsets, "sfem_exchange_classes: null pointer");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      exchange_classes_kernel<T>, dim3(stream_grid(num_classes * ncomp, 256)),
+      dim3(256), 0, as_stream(stream), (T*)u, members, offsets, num_classes,
+      ncomp, node_stride, comp_stride));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_zero_strips(void* base, int64_t strip_len, int64_t strip_stride,
+                     int nstrips, int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(strip_len >= 0 && nstrips >= 0 && strip_stride >= 0,
+               "sfem_zero_strips: bad sizes");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_zero_strips: unknown dtype %d", dtype);
+  if (strip_len == 0 || nstrips == 0) return SFEM_OK;
+  SFEM_REQUIRE(base, "sfem_zero_strips: null pointer");
+  const size_t esz = dtype == SFEM_F64 ? 8 : 4;
+  // large ranges: the runtime's fill runs at stream bandwidth; short ones are
+  // bound by the number of launches, so all strips go into one
+  if ((size_t)strip_len * esz >= ((size_t)8 << 20)) {
+    for (int s = 0; s < nstrips; ++s)
+      SFEM_HIP(hipMemsetAsync((char*)base + (size_t)s * strip_stride * esz, 0,
+                              (size_t)strip_len * esz, as_stream(stream)));
+    return SFEM_OK;
+  }
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(
+      zero_strips_kernel<T>, dim3(stream_grid(strip_len * nstrips, 256)),
+      dim3(256), 0, as_stream(stream), (T*)base, strip_len, strip_stride,
+      nstrips));
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_subtract_weighted_mean(const void* w, const void* b, double total,
+                                void* out, double* partials, int64_t count,
+                                int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0, "sfem_subtract_weighted_mean: bad count");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_subtract_weighted_mean: unknown dtype %d", dtype);
+  SFEM_REQUIRE(total != 0.0, "sfem_subtract_weighted_mean: total is zero");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(w && b && out && partials,
+               "sfem_subtract_weighted_mean: null pointer");
+  int64_t nblk = (count + 512 * 4 - 1) / (512 * 4);
+  if (nblk > SFEM_DOT_SLOTS) nblk = SFEM_DOT_SLOTS;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL(dot_partials_kernel<T>, dim3((unsigned)nblk), dim3(512),
+                       0, as_stream(stream), (const T*)w, (const T*)b, count,
+                       partials);
+    hipLaunchKernelGGL(subtract_mean_kernel<T>,
+                       dim3(stream_grid(count, 512)), dim3(512), 0,
+                       as_stream(stream), (const T*)w, partials, (int)nblk,
+                       1.0 / total, (T*)out, count);
   });
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;

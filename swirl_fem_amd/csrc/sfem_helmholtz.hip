@@ -224,22 +224,21 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   SFEM_REQUIRE(a->out, "sfem_helmholtz_apply: null out");
   const size_t esz = a->dtype == SFEM_F64 ? 8 : 4;
   if (a->zero_end > a->zero_begin) {
+    // shared nodes are accumulated with atomics: clear their range first
+    int rc0;
     if (a->node_stride > 0 && a->node_stride != a->ncomp) {
       // component-major layout: one contiguous strip per component
       SFEM_REQUIRE(a->node_stride == 1,
                    "sfem_helmholtz_apply: unsupported vector layout");
-      for (int k = 0; k < a->ncomp; ++k)
-        SFEM_HIP(hipMemsetAsync(
-            (char*)a->out +
-                ((size_t)k * a->comp_stride + a->zero_begin) * esz,
-            0, (size_t)(a->zero_end - a->zero_begin) * esz,
-            as_stream(stream)));
+      rc0 = sfem_zero_strips((char*)a->out + (size_t)a->zero_begin * esz,
+                             a->zero_end - a->zero_begin, a->comp_stride,
+                             a->ncomp, a->dtype, stream);
     } else {
-      SFEM_HIP(hipMemsetAsync(
-          (char*)a->out + (size_t)a->zero_begin * a->ncomp * esz, 0,
-          (size_t)(a->zero_end - a->zero_begin) * a->ncomp * esz,
-          as_stream(stream)));
+      rc0 = sfem_zero_strips(
+          (char*)a->out + (size_t)a->zero_begin * a->ncomp * esz,
+          (a->zero_end - a->zero_begin) * a->ncomp, 0, 1, a->dtype, stream);
     }
+    if (rc0) return rc0;
   }
   if (a->num_elements == 0) return SFEM_OK;
   SFEM_REQUIRE(a->u && a->enc && a->dmat, "sfem_helmholtz_apply: null pointer");

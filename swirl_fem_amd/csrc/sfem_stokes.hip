@@ -151,16 +151,15 @@ int sfem_stokes_grad_t(const sfem_stokes_args* a, sfem_stream_t stream) {
     // shared nodes are accumulated with atomics: clear their range first
     const int64_t nstr = a->node_stride > 0 ? a->node_stride : a->ndim;
     const int64_t cstr = a->node_stride > 0 ? a->comp_stride : 1;
-    if (cstr == 1) {
-      SFEM_HIP(hipMemsetAsync((char*)a->out + a->zero_begin * nstr * sz, 0,
-                              (a->zero_end - a->zero_begin) * nstr * sz,
-                              as_stream(stream)));
-    } else {
-      for (int c = 0; c < a->ndim; ++c)
-        SFEM_HIP(hipMemsetAsync(
-            (char*)a->out + (c * cstr + a->zero_begin * nstr) * sz, 0,
-            (a->zero_end - a->zero_begin) * nstr * sz, as_stream(stream)));
-    }
+    const int rc0 =
+        cstr == 1
+            ? sfem_zero_strips((char*)a->out + a->zero_begin * nstr * sz,
+                               (a->zero_end - a->zero_begin) * nstr, 0, 1,
+                               a->dtype, stream)
+            : sfem_zero_strips((char*)a->out + a->zero_begin * nstr * sz,
+                               (a->zero_end - a->zero_begin) * nstr, cstr,
+                               a->ndim, a->dtype, stream);
+    if (rc0) return rc0;
   }
   if (work == 0) return SFEM_OK;
   if (a->dtype == SFEM_F64) return run_stokes<double>(a, 1, as_stream(stream));

@@ -46,6 +46,7 @@ from swirl_fem_amd.core.mesh import Mesh
 from swirl_fem_amd.core.mesh_refiner import refine_premesh
 from swirl_fem_amd.core.premesh import Premesh
 from swirl_fem_amd.linalg.cg import cg
+from swirl_fem_amd import _lib
 from swirl_fem_amd import _ops
 
 # pylint: disable=invalid-name
@@ -84,6 +85,14 @@ def _pressure_project_out_nullspace(sem, p):
     b1 = sem.pressure.B(torch.ones_like(p))
     sem._cache[key] = (b1, sem._global_sum(torch.sum(b1).reshape(1)))
   b1, total = sem._cache[key]
+  if not sem.is_partitioned:
+    # one partition: dot and subtraction as two launches, nothing on the host
+    if 'project_partials' not in sem._cache:
+      sem._cache['project_partials'] = (
+          torch.empty(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
+                      device=p.device), float(total))
+    partials, total_host = sem._cache['project_partials']
+    return _ops.subtract_weighted_mean(w, b1, total_host, partials)
   return w - sem._global_sum(torch.vdot(b1, w).reshape(1)) / total
 
 

@@ -147,6 +147,58 @@ def test_exchange_reference_known_answers():
   np.testing.assert_allclose(out.cpu().numpy(), np.arange(6.))
 
 
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_exchange_classes_layouts_and_workspace_form(dtype):
+  """`sfem_exchange_classes` (one launch, in place, every layout) against the
+  oracle and against the C-ABI's workspace form `sfem_exchange_local`."""
+  from swirl_fem_amd import _ops
+  from swirl_fem_amd.core import layout
+  rp = make_case(3, 3, 4, periodic=(0, 1, 2))
+  mesh = rp.finalize(device=DEV)
+  arrs = rp.finalize_all()
+  gi, ui = arrs['exchange_gather_indices'], arrs['exchange_unique_indices']
+  u = np.random.default_rng(9).standard_normal((mesh.num_nodes, 3))
+  ref = np.stack([O.exchange_unpartitioned(u[:, k], gi, ui)
+                  for k in range(3)], axis=-1)
+  tol = 1e-14 if dtype == torch.float64 else 1e-6
+  ud, gd = dev(u, dtype), dev(gi)
+  assert relerr(_ops.exchange_local(ud[:, 0].contiguous(), gd, ui),
+                ref[:, 0]) < tol
+  assert relerr(_ops.exchange_local(ud, gd, ui), ref) < tol
+  cm = layout.component_major(ud)
+  out = _ops.exchange_local(cm, gd, ui)
+  assert layout.is_component_major(out) and relerr(out, ref) < tol
+  w = ud.clone()
+  assert _ops.exchange_local(w, gd, ui, inplace=True) is w
+  assert relerr(w, ref) < tol
+  assert relerr(_ops.exchange_local_atomic(ud, gd, ui), ref) < tol
+  # bitwise reproducible (member order), unlike the atomic form
+  assert torch.equal(_ops.exchange_local(ud, gd, ui),
+                     _ops.exchange_local(ud, gd, ui))
+
+
+@pytest.mark.parametrize('dtype,n', [(torch.float64, 5), (torch.float64, 70001),
+                                     (torch.float32, 4099),
+                                     (torch.float64, 3000000)])
+def test_subtract_weighted_mean(dtype, n):
+  """The pressure nullspace projection w - (b.w / 1.b) 1 (reference
+  navier_stokes.py:73-78 with b = B 1)."""
+  from swirl_fem_amd import _lib, _ops
+  g = torch.Generator(device=DEV).manual_seed(n)
+  w = torch.randn(n, dtype=dtype, device=DEV, generator=g)
+  b = torch.rand(n, dtype=dtype, device=DEV, generator=g) + 0.5
+  total = float(b.double().sum())
+  partials = torch.full((_lib.SFEM_DOT_SLOTS,), float('nan'),
+                        dtype=torch.float64, device=DEV)   # need not be cleared
+  out = _ops.subtract_weighted_mean(w, b, total, partials)
+  want = w.double() - torch.dot(b.double(), w.double()) / total
+  assert relerr(out.double(), want.cpu().numpy()) < TOL[dtype]
+  assert abs(float(torch.dot(b.double(), out.double())) / total) < (
+      1e-12 if dtype == torch.float64 else 1e-5)
+  assert _ops.subtract_weighted_mean(w, b, total, partials, out=w) is w
+  assert relerr(w.double(), want.cpu().numpy()) < TOL[dtype]
+
+
 @pytest.mark.parametrize('ndim,per', [(2, (0,)), (2, (0, 1)), (3, (0, 1, 2))])
 def test_exchange_periodic_refined(ndim, per):
   rp = make_case(ndim, 3, 4, periodic=per)
