@@ -19,7 +19,9 @@ def _mats(interp, like):
 def interp(interpolator, u3):
   """u3 (E, n, nc) -> (E, Q, nc)."""
   i1, g1 = _mats(interpolator, u3)
-  val, _ = _ops.basis_eval(
+  from swirl_fem_amd.core import autodiff
+  ev = autodiff.basis_eval if autodiff.needs_grad(u3) else _ops.basis_eval
+  val, _ = ev(
       u3, i1, g1, None, interpolator.ndim,
       interpolator.gridpoints_1d.num_points,
       interpolator.evalpoints_1d.num_points, False, True, False)

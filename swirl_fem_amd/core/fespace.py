@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from swirl_fem_amd import _ops
+from swirl_fem_amd.core import autodiff
 from swirl_fem_amd.core import interpolation
 from swirl_fem_amd.core.interpolation import BarycentricInterpolator
 from swirl_fem_amd.core.interpolation import Quadrature1D
@@ -257,7 +258,8 @@ class FiniteElementSpace:
     """u3 (E, n, nc) -> values (E,Q,nc), physical gradients (E,Q,d,nc)."""
     i1, g1 = self._matrices()
     u3 = u3.to(self.dtype)
-    return _ops.basis_eval(
+    ev = autodiff.basis_eval if autodiff.needs_grad(u3) else _ops.basis_eval
+    return ev(
         u3, i1, g1, self.invjacs if want_grad else None, self.mesh.ndim,
         self.mesh.gridpoints_1d.num_points, self.quadrature.num_points,
         self.is_collocated, want_val, want_grad)
@@ -334,7 +336,9 @@ class FiniteElementSpace:
     if c1 is not None:
       c1 = c1.to(self.dtype).reshape(E, Q, d, nc)
     i1, g1 = self._matrices()
-    out = _ops.basis_eval_t(
+    ev_t = (autodiff.basis_eval_t if autodiff.needs_grad(c0, c1)
+            else _ops.basis_eval_t)
+    out = ev_t(
         c0, c1, i1, g1, self.invjacs, self.wdet(), d,
         self.mesh.gridpoints_1d.num_points, self.quadrature.num_points, nc,
         self.is_collocated)

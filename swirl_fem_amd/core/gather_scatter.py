@@ -37,6 +37,9 @@ def gather(u, indices, fill_value=SENTINEL):
   from swirl_fem_amd import _ops
   if u.ndim != 1:
     raise ValueError(f'Expecting a rank-1 array. Got {tuple(u.shape)}')
+  from swirl_fem_amd.core import autodiff
+  if autodiff.needs_grad(u):
+    return autodiff.gather(u, indices, float(fill_value))
   return _ops.gather(u, indices, float(fill_value))
 
 
@@ -45,6 +48,9 @@ def scatter(u, indices, num_nodes: int):
   from swirl_fem_amd import _ops
   assert tuple(u.shape) == tuple(indices.shape), (
       f'Got: {tuple(u.shape)} v/s {tuple(indices.shape)}')
+  from swirl_fem_amd.core import autodiff
+  if autodiff.needs_grad(u):
+    return autodiff.scatter_add(u, indices, int(num_nodes))
   return _ops.scatter_add(u, indices, int(num_nodes))
 
 
@@ -68,6 +74,9 @@ def exchange(u, gather_indices, unique_indices=None, axis_name=None, *,
     if unique_indices is None:
       # Every participating DOF is its own class: QQ^T is the identity.
       return u.clone()
+    from swirl_fem_amd.core import autodiff
+    if autodiff.needs_grad(u):
+      return autodiff.exchange_local(u, gather_indices, unique_indices)
     return _ops.exchange_local(u, gather_indices, unique_indices)
   from swirl_fem_amd.distributed import comm
   if plan is None:

@@ -286,8 +286,10 @@ class _SymmetricSolve(torch.autograd.Function):
   """x = A^-1 b with the adjoint solved by the same routine (A symmetric)."""
 
   @staticmethod
-  def forward(ctx, b, A, kwargs):
+  def forward(ctx, b, A, kwargs, info_out):
     x, info = cg(A, b.detach(), **kwargs)
+    if info_out is not None:
+      info_out.update(info)
     ctx.A, ctx.kwargs = A, kwargs
     return x
 
@@ -295,13 +297,14 @@ class _SymmetricSolve(torch.autograd.Function):
   def backward(ctx, grad_x):
     # d<x, g>/db = A^-T g = A^-1 g
     grad_b, _ = cg(ctx.A, grad_x.detach().contiguous(), **ctx.kwargs)
-    return grad_b, None, None
+    return grad_b, None, None, None
 
 
-def symmetric_solve(A, b, **kwargs):
+def symmetric_solve(A, b, info_out=None, **kwargs):
   """`cg(A, b, **kwargs)[0]` that autograd can differentiate with respect to
   `b`: the cotangent is obtained by a second solve with the same symmetric
   operator, which is what `lax.custom_linear_solve(symmetric=True)` does for
   the reference's solves (navier_stokes/navier_stokes.py:436-452).  Gradients
-  with respect to tensors hidden inside `A` are not propagated."""
-  return _SymmetricSolve.apply(b, A, kwargs)
+  with respect to tensors hidden inside `A` are not propagated.  `info_out`: a
+  dict that receives the forward solve's `info`."""
+  return _SymmetricSolve.apply(b, A, kwargs, info_out)

@@ -32,6 +32,7 @@ from typing import Any
 import numpy as np
 import torch
 
+from swirl_fem_amd.core import autodiff
 from swirl_fem_amd.core import basis
 from swirl_fem_amd.core import layout
 from swirl_fem_amd.core import operators
@@ -46,6 +47,7 @@ from swirl_fem_amd.core.mesh import Mesh
 from swirl_fem_amd.core.mesh_refiner import refine_premesh
 from swirl_fem_amd.core.premesh import Premesh
 from swirl_fem_amd.linalg.cg import cg
+from swirl_fem_amd.linalg.cg import symmetric_solve
 from swirl_fem_amd import _lib
 from swirl_fem_amd import _ops
 
@@ -72,6 +74,16 @@ def bdfk_coeffs(k: int) -> np.ndarray:
       ndim=1, gridpoints_1d=gridpoints, evalpoints_1d=evalpoints)
   h = 2 / k
   return interpolator.interpolation_matrix_grad().reshape((-1)) * h
+
+
+def _solve(differentiable, A, b, **kwargs):
+  """`cg(A, b, **kwargs)`; with `differentiable`, autograd sees the solve as
+  `x = A^-1 b` (adjoint by a second solve, `linalg.cg.symmetric_solve`)."""
+  if not differentiable:
+    return cg(A, b, **kwargs)
+  info = {}
+  x = symmetric_solve(A, b, info_out=info, **kwargs)
+  return x, info
 
 
 def _pressure_project_out_nullspace(sem, p):
@@ -233,10 +245,15 @@ class StokesVelocity:
 
   def gather(self, u):
     """(N, d) -> (E, n, d)."""
+    if autodiff.needs_grad(u):
+      return autodiff.gather_rows(u, self.mesh.elements)
     return _ops.gather_rows(u, self.mesh.elements)
 
   def scatter(self, u):
     """(E, n, d) -> (N, d)."""
+    if autodiff.needs_grad(u):
+      return autodiff.scatter_add(u, self.mesh.elements, self.mesh.num_nodes,
+                                  ncomp=u.shape[-1])
     return _ops.scatter_add(u, self.mesh.elements, self.mesh.num_nodes,
                             ncomp=u.shape[-1])
 
@@ -249,8 +266,12 @@ class StokesVelocity:
     if mesh.axis_name is None:
       if mesh.exchange_unique_indices is None:
         return u if inplace else u.clone()
+      if autodiff.needs_grad(u):
+        return autodiff.exchange_local(u, gi, mesh.exchange_unique_indices)
       return _ops.exchange_local(u, gi, mesh.exchange_unique_indices,
                                  inplace=inplace)
+    if autodiff.needs_grad(u):
+      raise NotImplementedError('autograd through the partitioned exchange')
     from swirl_fem_amd.distributed import comm
     if inplace:
       return comm.neighbor_exchange_(u, mesh.neighbor_plan)
@@ -264,7 +285,7 @@ class StokesVelocity:
 
   def A_local(self, u_local):
     """Apply the velocity stiffness operator locally."""
-    op = self._fused()
+    op = None if autodiff.needs_grad(u_local) else self._fused()
     if op is not None:
       return op.apply_local(u_local, 0.0, 1.0)
 
@@ -277,7 +298,7 @@ class StokesVelocity:
 
   def B_local(self, u_local):
     """Apply the velocity mass operator locally."""
-    op = self._fused()
+    op = None if autodiff.needs_grad(u_local) else self._fused()
     if op is not None:
       return op.apply_local(u_local, 1.0, 0.0)
 
@@ -297,7 +318,8 @@ class StokesVelocity:
             self.overint_space)
       except NotImplementedError:      # fall back to the generic form below
         cache['convection'] = None
-    if cache['convection'] is not None:
+    # (the generic form below is what autograd can differentiate)
+    if cache['convection'] is not None and not autodiff.needs_grad(u_local):
       return cache['convection'].apply_local(u_local)
 
     def c(u, w, v):
@@ -394,7 +416,7 @@ class StokesSEM:
 
   def A(self, u):
     """Apply the stiffness operator to a velocity field."""
-    op = self._masked_operator()
+    op = None if autodiff.needs_grad(u) else self._masked_operator()
     if op is not None:
       return op.apply(u, 0.0, 1.0)
     return self.velocity.interior_mask * self.velocity.scatter(
@@ -403,7 +425,7 @@ class StokesSEM:
   def H(self, u, mass_coeff: float, mu: float):
     """Helmholtz operator `mass_coeff * B + mu * A` (reference :431) in one
     fused kernel; equals `mass_coeff * self.B(u) + mu * self.A(u)`."""
-    op = self._masked_operator()
+    op = None if autodiff.needs_grad(u) else self._masked_operator()
     if op is not None:
       return op.apply(u, mass_coeff, mu)
     return mass_coeff * self.B(u) + mu * self.A(u)
@@ -445,14 +467,14 @@ class StokesSEM:
 
   def D(self, u):
     """Velocity divergence matrix."""
-    op = self._divgrad()
+    op = None if autodiff.needs_grad(u) else self._divgrad()
     if op is not None:
       return op.div(u)
     return self.pressure.scatter(self.D_local(self.velocity.gather(u)))
 
   def Dt(self, p):
     """Apply the pressure gradient operator."""
-    op = self._divgrad()
+    op = None if autodiff.needs_grad(p) else self._divgrad()
     if op is not None:
       return op.grad_t(p)
     return self.velocity.interior_mask * self.velocity.scatter(
@@ -465,7 +487,7 @@ class StokesSEM:
 
   def E(self, p, dt: float, time_order: int):
     """Apply the operator E = D Q D^T."""
-    op = self._divgrad()
+    op = None if autodiff.needs_grad(p) else self._divgrad()
     if op is not None:
       # two kernels: D^T, then D with Q = (dt / beta_k) diag(QQ^T B)^-1 folded
       # into its gather (plus the exchange on periodic / partitioned meshes)
@@ -517,17 +539,26 @@ class StokesSEM:
     # (iterations on small meshes are launch-bound); SFEM_GRAPHS=0 disables it
     graph = (self.velocity.mesh.axis_name is None and
              os.environ.get('SFEM_GRAPHS', '1') != '0')
-    u_star, info = cg(H_, f, M=self.velocity.exchange, tol=tol, atol=atol,
-                      graph=graph, reduce_fn=self._reduce_fn())
+    # differentiable step (reference: lax.custom_linear_solve(symmetric=True),
+    # :436-452): the cotangent of a solve is one more solve
+    diff = autodiff.needs_grad(f, u_boundary, *us, *ps)
+    if diff:
+      # f and u_star vanish on the Dirichlet rows; saying so to autograd keeps
+      # the cotangent solve on the same (masked) system
+      f = self.velocity.interior_mask * f
+    u_star, info = _solve(diff, H_, f, M=self.velocity.exchange, tol=tol,
+                          atol=atol, graph=graph, reduce_fn=self._reduce_fn())
+    if diff:
+      u_star = self.velocity.interior_mask * u_star
     if u_boundary is not None:
       u_star = u_star + u_boundary
     aux = {'u_star_info': info}
 
     u_star = self.filter(u_star, alpha=alpha)
 
-    dp, info = cg(partial(self.E, dt=dt, time_order=time_order),
-                  -self.D(u_star), M=pressure_preconditioner, tol=tol,
-                  atol=atol, graph=graph, reduce_fn=self._reduce_fn())
+    dp, info = _solve(diff, partial(self.E, dt=dt, time_order=time_order),
+                      -self.D(u_star), M=pressure_preconditioner, tol=tol,
+                      atol=atol, graph=graph, reduce_fn=self._reduce_fn())
     aux['dp_info'] = info
 
     u = u_star + self.Q(self.Dt(dp), dt=dt, time_order=time_order)
