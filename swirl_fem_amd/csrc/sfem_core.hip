@@ -254,6 +254,36 @@ struct Vec16<float> {
   static constexpr int N = 4;
 };
 
+// Non-temporal 16-byte accesses for vectors that are streamed once per kernel.
+template <typename T>
+struct NativeVec16;
+template <>
+struct NativeVec16<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct NativeVec16<float> {
+  typedef float type __attribute__((ext_vector_type(4)));
+};
+
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type nt_load(
+    const typename Vec16<T>::type* p) {
+  using NV = typename NativeVec16<T>::type;
+  const NV v = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+  typename Vec16<T>::type out;
+  *reinterpret_cast<NV*>(&out) = v;
+  return out;
+}
+
+template <typename T>
+__device__ __forceinline__ void nt_store(const typename Vec16<T>::type& v,
+                                         typename Vec16<T>::type* p) {
+  using NV = typename NativeVec16<T>::type;
+  __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&v),
+                              reinterpret_cast<NV*>(p));
+}
+
 template <typename T>
 __device__ __forceinline__ T vget(const typename Vec16<T>::type& v, int i) {
   return reinterpret_cast<const T*>(&v)[i];
@@ -436,15 +466,15 @@ cg_update_r_kernel(T* __restrict__ r, const T* __restrict__ ap, int64_t count,
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += stride) {
-    V rr = rv[i];
-    const V aa = apv[i];
+    V rr = nt_load<T>(&rv[i]);
+    const V aa = nt_load<T>(&apv[i]);
 #pragma unroll
     for (int c = 0; c < VN; ++c) {
       T* re = reinterpret_cast<T*>(&rr) + c;
       *re -= alpha * vget<T>(aa, c);
       if (FUSE_RR) acc += (double)*re * (double)*re;
     }
-    rv[i] = rr;
+    nt_store<T>(rr, &rv[i]);
   }
   if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
     const int64_t i = nvec * VN + threadIdx.x;
@@ -475,8 +505,9 @@ cg_update_xp_kernel(T* __restrict__ x, T* __restrict__ p,
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += stride) {
-    V xx = xv[i], pp = pv[i];
-    const V zz = zv[i];
+    V xx = nt_load<T>(&xv[i]);
+    V pp = nt_load<T>(&pv[i]);
+    const V zz = nt_load<T>(&zv[i]);
 #pragma unroll
     for (int c = 0; c < VN; ++c) {
       T* xe = reinterpret_cast<T*>(&xx) + c;
@@ -484,8 +515,8 @@ cg_update_xp_kernel(T* __restrict__ x, T* __restrict__ p,
       *xe += alpha * *pe;
       *pe = vget<T>(zz, c) + beta * *pe;
     }
-    xv[i] = xx;
-    pv[i] = pp;
+    nt_store<T>(xx, &xv[i]);
+    nt_store<T>(pp, &pv[i]);
   }
   if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
     const int64_t i = nvec * VN + threadIdx.x;
