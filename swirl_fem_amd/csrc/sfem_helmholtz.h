@@ -447,7 +447,9 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
     const int32_t* enc0 = prm.enc + e * N;
 #pragma unroll
     for (int a = 0; a < P; ++a)
-      enc[a] = active ? (uint32_t)enc0[slot_off + a * TPE]
+      // the index rows are streamed once per apply: keep them out of the L2
+      enc[a] = active ? (uint32_t)__builtin_nontemporal_load(
+                            &enc0[slot_off + a * TPE])
                       : (uint32_t)SFEM_IDX_PAD;
   }
   const T* ul0 = GS ? nullptr : prm.u + e * N * ns + prm.comp * ks;
