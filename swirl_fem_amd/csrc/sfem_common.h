@@ -53,6 +53,12 @@ inline unsigned stream_grid(int64_t work_items, int block) {
   return static_cast<unsigned>(blocks);
 }
 
+// A vector of this many bytes does not survive in the 256 MB Infinity Cache
+// between two kernels: streaming kernels then use non-temporal accesses.
+inline bool streams_past_caches(int64_t count, size_t elem_size) {
+  return (size_t)count * elem_size >= ((size_t)256 << 20);
+}
+
 // Kernels that end in one atomic per workgroup on ONE address (dot products,
 // the fused r.r): 16 workgroups per CU.  More helps the streaming part of a
 // 90 M-element vector by 1.5 % but the serialised atomics then dominate short
