@@ -324,6 +324,21 @@ int sfem_stokes_div(const sfem_stokes_args* args, sfem_stream_t stream);
 int sfem_stokes_convect_local(const sfem_stokes_args* args,
                               sfem_stream_t stream);
 int sfem_stokes_grad_t(const sfem_stokes_args* args, sfem_stream_t stream);
+/* E = D Q D^T (StokesSEM.E, navier_stokes.py:340-348) in two halves for a
+ * diagonal Q = `scale`.  A velocity node held by one element only, and not part
+ * of the periodic / partition exchange (`enc` must flag every other node
+ * SHARED), is complete after that element's D^T, so the first half keeps it
+ * in registers: scaled by Q it goes straight into the element's D.
+ *   sfem_stokes_e_first : p_in -> `out` (SHARED nodes only: zero-filled range +
+ *                         atomics; other entries are not written) and
+ *                         p_out = D (Q . complete part)
+ *   [caller: QQ^T exchange of `out` on the shared nodes]
+ *   sfem_stokes_e_second: p_out += D (Q . u restricted to the SHARED nodes)
+ * Same argument block as sfem_stokes_div / sfem_stokes_grad_t; `scale`
+ * applies in both halves.  At P = 8 in 3D 216 of the 512 nodes of an element
+ * never reach memory.                                                        */
+int sfem_stokes_e_first(const sfem_stokes_args* args, sfem_stream_t stream);
+int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
 
 /* ------------------------------------------------------------ CG kernels ---
  * Preconditioned CG of linalg/cg.py:30-97 with device-resident scalars: no

@@ -103,6 +103,8 @@ SIGNATURES = {
                           c_i32, c_ptr],
     'sfem_stokes_div': [c_ptr, c_ptr],
     'sfem_stokes_grad_t': [c_ptr, c_ptr],
+    'sfem_stokes_e_first': [c_ptr, c_ptr],
+    'sfem_stokes_e_second': [c_ptr, c_ptr],
     'sfem_stokes_convect_local': [c_ptr, c_ptr],
     'sfem_abi_version': [],
 }

@@ -513,6 +513,58 @@ def stokes_grad_t(p, out, enc, penc, parts, host, ndim, P, zero_range):
   return out
 
 
+def _scale_args(scale, field, ndim):
+  per_node = scale is not None and scale.dim() == 1
+  if per_node:
+    if scale.shape[0] != field.shape[0] or not scale.is_contiguous():
+      raise ValueError('per-node scale must be a contiguous (N,) vector')
+  elif scale is not None:
+    _check_field(scale, ndim)
+    if scale.stride() != field.stride():
+      raise ValueError('scale must share the layout of the velocity field')
+  if scale is not None and scale.dtype != field.dtype:
+    raise ValueError('scale must share the dtype of the velocity field')
+  return per_node
+
+
+def stokes_e_first(p, w, p_out, enc, penc, parts, host, ndim, P, zero_range,
+                   scale=None):
+  """First half of E = D Q D^T (`sfem_stokes_e_first`): `w` receives D^T p at
+  the SHARED nodes only, `p_out` = D(scale * complete part)."""
+  dev = _dev(enc, p, p_out)
+  _check_field(w, ndim)
+  per_node = _scale_args(scale, w, ndim)
+  host = {k: _host(v, w.dtype) for k, v in host.items()}
+  with torch.cuda.device(dev):
+    for n, part in enumerate(parts):
+      args = _stokes_args(w, enc, penc, part, host, ndim, P,
+                          zero_range if n == 0 else (0, 0),
+                          out=w.data_ptr(), p_in=p.data_ptr(),
+                          p_out=p_out.data_ptr(), scale=_dptr(scale),
+                          scale_per_node=int(per_node))
+      _lib.check(_lib.load().sfem_stokes_e_first(ctypes.byref(args),
+                                                 _stream(dev)),
+                 'sfem_stokes_e_first')
+  return p_out
+
+
+def stokes_e_second(w, p_out, enc, penc, parts, host, ndim, P, scale=None):
+  """Second half: p_out += D(scale * w restricted to the SHARED nodes)."""
+  dev = _dev(enc, p_out)
+  _check_field(w, ndim)
+  per_node = _scale_args(scale, w, ndim)
+  host = {k: _host(v, w.dtype) for k, v in host.items()}
+  with torch.cuda.device(dev):
+    for part in parts:
+      args = _stokes_args(w, enc, penc, part, host, ndim, P, (0, 0),
+                          u=w.data_ptr(), p_out=p_out.data_ptr(),
+                          scale=_dptr(scale), scale_per_node=int(per_node))
+      _lib.check(_lib.load().sfem_stokes_e_second(ctypes.byref(args),
+                                                  _stream(dev)),
+                 'sfem_stokes_e_second')
+  return p_out
+
+
 def stokes_convect_local(u_local, parts, host, ndim, P):
   """(E, P^d, d) values on a collocated grid -> w detJ (u . grad) u there."""
   u_local = u_local.contiguous()

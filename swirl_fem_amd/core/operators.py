@@ -324,6 +324,8 @@ class StokesDivGrad:
   host: dict
   zero_range: tuple
   num_pressure_nodes: int
+  dirichlet_u8: torch.Tensor | None = None
+  _split: tuple | None = None
 
   @classmethod
   def create(cls, vspace, pspace, dirichlet_mask=None,
@@ -382,7 +384,60 @@ class StokesDivGrad:
             'interp': pspace.interpolator._interpolation_matrix_1d()}
     return cls(vspace=vspace, pspace=pspace, parts=parts, enc=enc, penc=penc,
                host=host, zero_range=plan.zero_range,
-               num_pressure_nodes=pspace.mesh.num_nodes)
+               num_pressure_nodes=pspace.mesh.num_nodes, dirichlet_u8=mask)
+
+  def _split_encoding(self):
+    """`enc` with every node of the periodic / partition exchange flagged
+    SHARED too, and the node range that then needs clearing: what the split
+    `E` (`sfem_stokes_e_first` / `_second`) assumes."""
+    if self._split is None:
+      mesh = self.vspace.mesh
+      mult = mesh.assembly_plan().multiplicity.clone()
+      ids = []
+      gi = mesh.exchange_gather_indices
+      if gi is not None and gi.numel():
+        ids.append(gi[gi >= 0].to(torch.int64))
+      if mesh.neighbor_plan is not None:
+        ids.append(mesh.neighbor_plan.interface_nodes(mult.device).to(
+            torch.int64))
+      if ids:
+        idx = torch.cat(ids)
+        mult[idx] = torch.clamp(mult[idx], min=2)
+      other = torch.nonzero(mult != 1).reshape(-1)
+      rng = (int(other.min()), int(other.max()) + 1) if other.numel() else (0, 0)
+      enc = _ops.encode_elements(mesh.elements, self.dirichlet_u8, mult)
+      self._split = (enc, rng)
+    return self._split
+
+  def e_apply(self, p, scale=None, exchange=None):
+    """(Np,) -> (Np,):  D [ scale * QQ^T (mask * D^T p) ] = `StokesSEM.E` for a
+    diagonal Q, with the element-interior velocity nodes kept in registers
+    (`sfem_stokes_e_first` / `sfem_stokes_e_second`).  `exchange(w)` applies
+    QQ^T in place to the (N, d) component-major intermediate, of which only
+    the shared nodes are defined; None on a mesh without periodic images or
+    partitions."""
+    mesh = self.vspace.mesh
+    if self.penc is not None:
+      raise NotImplementedError('split E needs element-local pressure nodes')
+    if tuple(p.shape) != (self.num_pressure_nodes,):
+      raise ValueError(f'expected ({self.num_pressure_nodes},) pressure, got '
+                       f'{tuple(p.shape)}')
+    from swirl_fem_amd.core import layout
+    p = p.to(self.vspace.dtype).contiguous()
+    enc, zero_range = self._split_encoding()
+    w = layout.empty_component_major((mesh.num_nodes, mesh.ndim), p.dtype,
+                                     p.device)
+    if scale is not None:
+      scale = scale.to(p.dtype)
+      scale = (scale.contiguous() if scale.dim() == 1
+               else _like_layout(scale.expand_as(w), w))
+    out = torch.empty(self.num_pressure_nodes, dtype=p.dtype, device=p.device)
+    args = (enc, self.penc, self.parts, self.host, mesh.ndim,
+            mesh.gridpoints_1d.num_points)
+    _ops.stokes_e_first(p, w, out, *args, zero_range, scale)
+    if exchange is not None:
+      w = exchange(w)
+    return _ops.stokes_e_second(w, out, *args, scale)
 
   def div(self, u, scale=None, out=None):
     """(N, d) -> (Np,):  D (scale * u); `scale` is (N, d) or (N,)."""

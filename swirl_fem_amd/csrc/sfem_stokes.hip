@@ -166,4 +166,49 @@ int sfem_stokes_grad_t(const sfem_stokes_args* a, sfem_stream_t stream) {
   return run_stokes<float>(a, 1, as_stream(stream));
 }
 
+// zero-fill of the shared-node range of `out` (all components)
+static int zero_shared_range(const sfem_stokes_args* a, sfem_stream_t stream) {
+  if (a->zero_end <= a->zero_begin) return SFEM_OK;
+  const size_t sz = a->dtype == SFEM_F64 ? 8 : 4;
+  const int64_t nstr = a->node_stride > 0 ? a->node_stride : a->ndim;
+  const int64_t cstr = a->node_stride > 0 ? a->comp_stride : 1;
+  return cstr == 1
+             ? sfem_zero_strips((char*)a->out + a->zero_begin * nstr * sz,
+                                (a->zero_end - a->zero_begin) * nstr, 0, 1,
+                                a->dtype, stream)
+             : sfem_zero_strips((char*)a->out + a->zero_begin * nstr * sz,
+                                (a->zero_end - a->zero_begin) * nstr, cstr,
+                                a->ndim, a->dtype, stream);
+}
+
+int sfem_stokes_e_first(const sfem_stokes_args* a, sfem_stream_t stream) {
+  int rc = check_stokes("sfem_stokes_e_first", a);
+  if (rc) return rc;
+  SFEM_REQUIRE(a->num_elements == 0 || (a->enc && a->interp),
+               "sfem_stokes_e_first: null pointer");
+  SFEM_REQUIRE(a->zero_begin >= 0 && a->zero_end >= a->zero_begin &&
+                   a->zero_end <= a->num_nodes,
+               "sfem_stokes_e_first: bad zero range");
+  const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
+  if (work == 0 && a->zero_end == a->zero_begin) return SFEM_OK;
+  SFEM_REQUIRE(a->out && (work == 0 || (a->p_in && a->p_out)),
+               "sfem_stokes_e_first: null pointer");
+  rc = zero_shared_range(a, stream);
+  if (rc) return rc;
+  if (work == 0) return SFEM_OK;
+  if (a->dtype == SFEM_F64) return run_stokes<double>(a, 3, as_stream(stream));
+  return run_stokes<float>(a, 3, as_stream(stream));
+}
+
+int sfem_stokes_e_second(const sfem_stokes_args* a, sfem_stream_t stream) {
+  int rc = check_stokes("sfem_stokes_e_second", a);
+  if (rc) return rc;
+  SFEM_REQUIRE(a->enc && a->interp, "sfem_stokes_e_second: null pointer");
+  const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
+  if (work == 0) return SFEM_OK;
+  SFEM_REQUIRE(a->u && a->p_out, "sfem_stokes_e_second: null pointer");
+  if (a->dtype == SFEM_F64) return run_stokes<double>(a, 4, as_stream(stream));
+  return run_stokes<float>(a, 4, as_stream(stream));
+}
+
 }  // extern "C"

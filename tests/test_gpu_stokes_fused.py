@@ -117,6 +117,65 @@ def test_div_and_grad_t_match_oracle(ndim, n, P, dtype):
           abs(lhs), 1.0)
 
 
+@pytest.mark.parametrize('ndim,n,P', [(2, 3, 4), (2, 4, 6), (2, 2, 12),
+                                      (3, 2, 4), (3, 2, 5), (3, 2, 8),
+                                      (3, 1, 12)])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_split_pressure_operator_matches_oracle(ndim, n, P, dtype):
+  """E = D Q D^T in two halves (`sfem_stokes_e_first` / `_second`: nodes held
+  by one element stay in registers) against the oracle's composition of
+  navier_stokes.py:313-348 and against the two-kernel path."""
+  tol = 1e-10 if dtype == torch.float64 else 1e-4
+  for shear, jitter in ((True, 0.0), (False, 0.15)):
+    rng, vsp, psp, ov, op = build(ndim, n, P, dtype, jitter=jitter,
+                                  shear=shear)
+    mesh = vsp.mesh
+    bmask = mesh.physical_masks['boundary']
+    p = rng.standard_normal(psp.mesh.num_nodes)
+    keep = (~bmask.cpu().numpy())[:, None]
+    g = keep * ov.scatter(O.div_t_local(ov, op, op.gather(p)))
+    for scale in (None, rng.uniform(0.5, 2.0, mesh.num_nodes),
+                  rng.uniform(0.5, 2.0, (mesh.num_nodes, ndim))):
+      sc = 1.0 if scale is None else (scale[:, None] if scale.ndim == 1
+                                      else scale)
+      ref = op.scatter(O.div_local(ov, op, ov.gather(sc * g)))
+      for geometry in ('auto', 'multilinear', 'stored'):
+        fused = operators.StokesDivGrad.create(vsp, psp, bmask, geometry)
+        pd = dev(p, dtype)
+        sd = None if scale is None else dev(scale, dtype)
+        got = fused.e_apply(pd, scale=sd)
+        assert relerr(got, ref) < tol, (geometry, shear, scale is None)
+        two = fused.div(fused.grad_t(pd, component_major=True), scale=sd)
+        assert relerr(got, two.double().cpu().numpy()) < tol
+
+
+def test_split_pressure_operator_with_periodic_images():
+  """Periodic images are complete only after the exchange: the split encoding
+  flags them shared although one element holds each of them."""
+  for ndim, order in ((2, 5), (3, 4)):
+    pm = unit_cube_mesh(3, ndim=ndim, periodic_dims=tuple(range(ndim)))
+    sem = StokesSEM.create(pm, {}, order=order, device=DEV)
+    op = sem._divgrad()
+    enc, rng = op._split_encoding()
+    gi = sem.velocity.mesh.exchange_gather_indices.to(torch.int64)
+    shared = torch.zeros(sem.velocity.mesh.num_nodes + 1, dtype=torch.bool,
+                         device=DEV)
+    flagged = (enc.to(torch.int64) & (1 << 30)) != 0      # SFEM_IDX_SHARED
+    shared[(enc.to(torch.int64) & ((1 << 30) - 1))[flagged]] = True
+    assert bool(shared[gi].all())
+    g = torch.Generator(device=DEV).manual_seed(1)
+    p = torch.randn(sem.pressure.pspace.mesh.num_nodes, dtype=torch.float64,
+                    device=DEV, generator=g)
+    got = sem.E(p, dt=1e-2, time_order=2)
+    want = sem.D(sem.Q(sem.Dt(p), dt=1e-2, time_order=2))
+    assert float((got - want).abs().max()) < 1e-11 * float(want.abs().max())
+    # symmetric positive semi-definite
+    q = torch.randn_like(p)
+    a = float((sem.E(q, dt=1e-2, time_order=2) * p).sum())
+    b = float((got * q).sum())
+    assert abs(a - b) < 1e-11 * max(abs(a), 1.0) and float((got * p).sum()) > 0
+
+
 @pytest.mark.parametrize('ndim,n,P', [(2, 4, 6), (3, 2, 5), (3, 2, 8)])
 def test_random_element_orientations(ndim, n, P):
   """Unstructured connectivity: rotated and reflected elements (signed
