@@ -252,6 +252,12 @@ typedef struct sfem_helmholtz_args {
   double* dot_out;        /* apply: NULL, or SFEM_DOT_SLOTS device doubles    */
                           /*   that accumulate partial sums of u . out (the   */
                           /*   p.Ap of CG, cg.py:78, for free in the scatter) */
+  const uint16_t* shared_order; /* apply: NULL, or (E, shared_stride): the    */
+  int32_t shared_stride;  /*   slots of each element's SHARED, non-Dirichlet  */
+                          /*   nodes in ascending node order, padded with     */
+                          /*   0xFFFF.  The atomics are then issued in that   */
+                          /*   order (values change lanes through LDS): twice */
+                          /*   the lanes per 64-byte line, same sums          */
 } sfem_helmholtz_args;
 #define SFEM_DOT_SLOTS 1024
 

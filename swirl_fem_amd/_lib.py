@@ -33,6 +33,7 @@ class HelmholtzArgs(ctypes.Structure):
       ('P', c_i32), ('ncomp', c_i32), ('dtype', c_i32), ('geo_mode', c_i32),
       ('colored', c_i32), ('lambda0', c_dbl), ('lambda1', c_dbl),
       ('node_stride', c_i64), ('comp_stride', c_i64), ('dot_out', c_ptr),
+      ('shared_order', c_ptr), ('shared_stride', c_i32),
   ]
 
 

@@ -395,6 +395,7 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
     # contiguous strip
     node_stride, comp_stride = 1, u.stride(-1)
   lst = part.get('elem_list')
+  so = part.get('shared_order')
   return _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),
       geo=_dptr(part.get('geo')), geo_elem=_dptr(part.get('geo_elem')),
@@ -407,7 +408,9 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       colored=int(bool(part.get('colored', False))), lambda0=float(lambda0),
       lambda1=float(lambda1), node_stride=node_stride,
       comp_stride=comp_stride,
-      dot_out=_dptr(dot_out))
+      dot_out=_dptr(dot_out),
+      shared_order=_dptr(so if enc is not None else None),
+      shared_stride=0 if so is None or enc is None else so.shape[1])
 
 
 def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,

@@ -21,6 +21,7 @@ q-function path (`FiniteElementSpace.local_covector`) when it says no.
 from __future__ import annotations
 
 import dataclasses
+import os
 
 import numpy as np
 import torch
@@ -185,6 +186,13 @@ class HelmholtzOperator:
       unref = torch.nonzero(plan.multiplicity == 0).reshape(-1)
       zero_range = ((int(unref.min()), int(unref.max()) + 1)
                     if unref.numel() else (0, 0))
+    if (assembly != 'colored' and mesh.ndim == 3 and
+        os.environ.get('SFEM_SORTED_SCATTER', '1') != '0'):
+      # 3D: most slots of an element are shared; issue their atomics in node
+      # order (better coalesced, see the kernel)
+      so = shared_slot_order(enc)
+      if so is not None:
+        parts = [dict(part, shared_order=so) for part in parts]
     host = {'dmat': fespace.interpolator._differentiation_matrix_1d(),
             'weights': np.asarray(fespace.quadrature.weights),
             'nodes': np.asarray(mesh.gridpoints_1d.node_values)}
@@ -310,6 +318,36 @@ def _sample_jacdets(space, elements):
       xe, i1, g1, mesh.ndim, mesh.gridpoints_1d.num_points,
       space.quadrature.num_points, want_quad_coords=False)
   return jacdets
+
+
+def shared_slot_order(enc):
+  """Per element, the slots of its SHARED non-Dirichlet nodes in ascending
+  node order: `(E, S)` int16 (bit pattern of uint16, 0xFFFF padded), S = the
+  largest count.  The assembled kernels issue their atomics in this order
+  (`sfem_helmholtz_args.shared_order`); None when no slot is shared."""
+  E, n = enc.shape
+  chunks, smax = [], 0
+  step = max(1, (1 << 25) // n)
+  for lo in range(0, E, step):
+    e64 = enc[lo:lo + step].to(torch.int64)
+    ids = e64 & 0x3FFFFFFF
+    take = ((e64 & (1 << 30)) != 0) & (e64 >= 0) & (ids != 0x3FFFFFFF)
+    key = torch.where(take, ids, torch.full_like(ids, 1 << 40))
+    order = torch.argsort(key, dim=1, stable=True)
+    count = take.sum(dim=1)
+    smax = max(smax, int(count.max()) if count.numel() else 0)
+    chunks.append((order, count))
+  if smax == 0:
+    return None
+  out = torch.empty((E, smax), dtype=torch.int16, device=enc.device)
+  col = torch.arange(smax, device=enc.device)[None, :]
+  at = 0
+  for order, count in chunks:
+    tab = order[:, :smax].to(torch.int32)
+    tab = torch.where(col < count[:, None], tab, torch.full_like(tab, 0xFFFF))
+    out[at:at + len(tab)] = tab.to(torch.int16)      # 0xFFFF wraps to -1
+    at += len(tab)
+  return out.contiguous()
 
 
 @dataclasses.dataclass(eq=False)

@@ -61,6 +61,10 @@ struct HelmholtzParams {
   double* dot_out;       // SFEM_DOT_SLOTS partial sums of u . out, or null
   int colored;           // launches are conflict-free colour classes: SHARED
                          // slots read-modify-write instead of atomics
+  // (E, shared_stride) slots of each element's SHARED, non-Dirichlet nodes in
+  // ascending node order, 0xFFFF padded; null = scatter in slot order
+  const uint16_t* shared_order;
+  int shared_stride;
 };
 
 __host__ __device__ constexpr int round_up(int a, int b) {
@@ -590,8 +594,54 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
       }
     }
     // direct-stiffness summation
+    const bool sorted = GS && prm.shared_order && !prm.colored;
+    if (sorted) {
+      // The atomics are bound by the number of memory-side requests, i.e. of
+      // 64-byte lines an instruction touches.  In slot order an instruction
+      // (fixed a, lanes (i, j)) meets 4 faces + 4 edges: ~3 lanes per line.
+      // In ascending NODE order consecutive lanes walk along a face or an edge
+      // (the refiner numbers facet interiors contiguously): 6-8 lanes per line.
+      // Values and codes change lanes through LDS (both copies are free here).
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        uint32_t ea = enc[a];
+        asm volatile("" : "+v"(ea));
+        const uint32_t id = ea & SFEM_IDX_MASK;
+        if (id != SFEM_IDX_PAD) {
+          const bool dirichlet = ea & SFEM_IDX_DIRICHLET;
+          if (!dirichlet) udot += (double)acc[a] * (double)ua[a];
+          if (!(ea & SFEM_IDX_SHARED))
+            og[(int64_t)id * ns + k * ks] = dirichlet ? T(0) : acc[a];
+        }
+      }
+      uint32_t* codes = reinterpret_cast<uint32_t*>(s1);
+      if (Tile::BLOCK > 64) __syncthreads();   // other waves still read s1
+      if (lane_ok) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+          s0[a * SA + i * SB + j] = acc[a];
+          codes[a * TPE + t] = enc[a];
+        }
+      }
+      __syncthreads();
+      if (active) {
+        const uint16_t* so = prm.shared_order + e * prm.shared_stride;
+        for (int q = t; q < prm.shared_stride; q += TPE) {
+          const uint32_t slot = so[q];
+          if (slot != 0xFFFFu) {
+            const uint32_t id = codes[slot] & SFEM_IDX_MASK;
+            const int a2 = slot / TPE, t2 = slot - a2 * TPE;
+            const int i2 = DIM == 3 ? t2 / P : 0;
+            const int j2 = DIM == 3 ? t2 - i2 * P : t2;
+            unsafeAtomicAdd(og + (int64_t)id * ns + k * ks,
+                            s0[a2 * SA + i2 * SB + j2]);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int a = 0; a < P; ++a) {
+      if (sorted) break;
       if (GS) {
         uint32_t ea = enc[a];
         // keep the flag tests inside the component loop (hoisting them costs

@@ -121,6 +121,8 @@ struct HelmholtzCall {
   double* dot_out;
   int colored;
   int64_t node_stride, comp_stride;
+  const uint16_t* shared_order = nullptr;
+  int shared_stride = 0;
 };
 
 template <typename T>
@@ -137,6 +139,8 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
   prm.comp = 0; prm.lambda0 = (T)c.l0; prm.lambda1 = (T)c.l1;
   prm.dot_out = c.dot_out;
   prm.colored = c.colored;
+  prm.shared_order = c.shared_order;
+  prm.shared_stride = c.shared_stride;
   if (c.ndim == 3) return dispatch_helmholtz<T, 3>(prm, c.P, c.gs, stream);
   if (c.ndim == 2) return dispatch_helmholtz<T, 2>(prm, c.P, c.gs, stream);
   set_error("helmholtz: ndim=%d (fused kernel supports 2 and 3)", c.ndim);
@@ -252,7 +256,11 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   HelmholtzCall c{a->u, a->out, a->enc, a->geo, a->geo_elem, a->geo_index,
                   a->elem_list, a->dmat, a->weights, a->nodes, work, a->ndim,
                   a->P, a->ncomp, a->geo_mode, a->lambda0, a->lambda1, true,
-                  a->dot_out, a->colored, a->node_stride, a->comp_stride};
+                  a->dot_out, a->colored, a->node_stride, a->comp_stride,
+                  a->shared_order, a->shared_stride};
+  SFEM_REQUIRE(!a->shared_order || (a->shared_stride > 0 &&
+                                    a->shared_stride <= 0xFFFF),
+               "sfem_helmholtz_apply: bad shared_stride");
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
 }
