@@ -315,6 +315,8 @@ typedef struct sfem_stokes_args {
   int64_t node_stride, comp_stride;  /* layout of u / out / scale (0 = (N, ndim)
                                         row-major)                             */
   int32_t scale_per_node; /* scale is one (N,) factor shared by the components */
+  const uint16_t* shared_order; /* grad_t / e_first: as in sfem_helmholtz_args, */
+  int32_t shared_stride;        /*   or NULL                                    */
 } sfem_stokes_args;
 
 int sfem_stokes_setup(const void* invjac, const void* jacdet,

@@ -15,7 +15,7 @@ Nv, Np = mesh.num_nodes, sem.pressure.pspace.mesh.num_nodes
 p = torch.randn(Np, dtype=torch.float64, device=dev)
 sem.E(p, dt=1e-3, time_order=3)
 scale = sem._cache[('q_scale', 1e-3, 3)]
-enc, zr = op._split_encoding()
+enc, zr, so = op._split_encoding()
 w = layout.empty_component_major((Nv, 3), torch.float64, dev)
 out = torch.empty(Np, dtype=torch.float64, device=dev)
 args = (enc, op.penc, op.parts, op.host, 3, 8)
@@ -28,6 +28,6 @@ shared = int(((enc.to(torch.int64) & (1 << 30)) != 0).sum())
 print('n=%d shared slots %.1f%%  zero range %.1f%% of nodes' % (n, 100 * shared / enc.numel(), 100 * (zr[1] - zr[0]) / Nv))
 print('grad_t(cm) %.3f  div(scale) %.3f | e_first %.3f  e_second %.3f  exchange %.3f ms' % (
     t(lambda: op.grad_t(p, out=w)), t(lambda: op.div(w, scale=scale, out=out)),
-    t(lambda: _ops.stokes_e_first(p, w, out, *args, zr, scale)),
+    t(lambda: _ops.stokes_e_first(p, w, out, *args, zr, scale, so)),
     t(lambda: _ops.stokes_e_second(w, out, *args, scale)),
     t(lambda: sem.velocity.exchange(w, inplace=True))))

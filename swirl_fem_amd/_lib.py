@@ -48,7 +48,8 @@ class StokesArgs(ctypes.Structure):
       ('zero_begin', c_i64), ('zero_end', c_i64), ('ndim', c_i32),
       ('P', c_i32), ('dtype', c_i32), ('geo_mode', c_i32),
       ('node_stride', c_i64), ('comp_stride', c_i64),
-      ('scale_per_node', c_i32),
+      ('scale_per_node', c_i32), ('shared_order', c_ptr),
+      ('shared_stride', c_i32),
   ]
 
 

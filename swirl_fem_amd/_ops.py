@@ -450,7 +450,8 @@ def stokes_setup(invjac, jacdet, weights_nd):
   return kfac
 
 
-def _stokes_args(vec, enc, penc, part, host, ndim, P, zero_range, **ptrs):
+def _stokes_args(vec, enc, penc, part, host, ndim, P, zero_range,
+                 shared_order=None, **ptrs):
   node_stride = comp_stride = 0
   if not vec.is_contiguous():
     node_stride, comp_stride = 1, vec.stride(-1)
@@ -465,7 +466,9 @@ def _stokes_args(vec, enc, penc, part, host, ndim, P, zero_range, **ptrs):
       num_nodes=vec.shape[0], zero_begin=int(zero_range[0]),
       zero_end=int(zero_range[1]), ndim=ndim, P=P, dtype=_dtype_code(vec),
       geo_mode=part['geo_mode'], node_stride=node_stride,
-      comp_stride=comp_stride, **ptrs)
+      comp_stride=comp_stride, shared_order=_dptr(shared_order),
+      shared_stride=0 if shared_order is None else shared_order.shape[1],
+      **ptrs)
 
 
 def _check_field(u, ndim):
@@ -500,7 +503,8 @@ def stokes_div(u, p_out, enc, penc, parts, host, ndim, P, scale=None):
   return p_out
 
 
-def stokes_grad_t(p, out, enc, penc, parts, host, ndim, P, zero_range):
+def stokes_grad_t(p, out, enc, penc, parts, host, ndim, P, zero_range,
+                  shared_order=None):
   """out <- mask * D^T p (navier_stokes.py:322-338)."""
   dev = _dev(enc, p)
   _check_field(out, ndim)
@@ -508,7 +512,7 @@ def stokes_grad_t(p, out, enc, penc, parts, host, ndim, P, zero_range):
   with torch.cuda.device(dev):
     for n, part in enumerate(parts):
       args = _stokes_args(out, enc, penc, part, host, ndim, P,
-                          zero_range if n == 0 else (0, 0),
+                          zero_range if n == 0 else (0, 0), shared_order,
                           out=out.data_ptr(), p_in=p.data_ptr())
       _lib.check(_lib.load().sfem_stokes_grad_t(ctypes.byref(args),
                                                 _stream(dev)),
@@ -531,7 +535,7 @@ def _scale_args(scale, field, ndim):
 
 
 def stokes_e_first(p, w, p_out, enc, penc, parts, host, ndim, P, zero_range,
-                   scale=None):
+                   scale=None, shared_order=None):
   """First half of E = D Q D^T (`sfem_stokes_e_first`): `w` receives D^T p at
   the SHARED nodes only, `p_out` = D(scale * complete part)."""
   dev = _dev(enc, p, p_out)
@@ -541,7 +545,7 @@ def stokes_e_first(p, w, p_out, enc, penc, parts, host, ndim, P, zero_range,
   with torch.cuda.device(dev):
     for n, part in enumerate(parts):
       args = _stokes_args(w, enc, penc, part, host, ndim, P,
-                          zero_range if n == 0 else (0, 0),
+                          zero_range if n == 0 else (0, 0), shared_order,
                           out=w.data_ptr(), p_in=p.data_ptr(),
                           p_out=p_out.data_ptr(), scale=_dptr(scale),
                           scale_per_node=int(per_node))

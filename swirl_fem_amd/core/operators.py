@@ -363,6 +363,7 @@ class StokesDivGrad:
   zero_range: tuple
   num_pressure_nodes: int
   dirichlet_u8: torch.Tensor | None = None
+  shared_order: torch.Tensor | None = None   # see `shared_slot_order`
   _split: tuple | None = None
 
   @classmethod
@@ -422,7 +423,14 @@ class StokesDivGrad:
             'interp': pspace.interpolator._interpolation_matrix_1d()}
     return cls(vspace=vspace, pspace=pspace, parts=parts, enc=enc, penc=penc,
                host=host, zero_range=plan.zero_range,
-               num_pressure_nodes=pspace.mesh.num_nodes, dirichlet_u8=mask)
+               num_pressure_nodes=pspace.mesh.num_nodes, dirichlet_u8=mask,
+               shared_order=cls._order(mesh, enc))
+
+  @staticmethod
+  def _order(mesh, enc):
+    if mesh.ndim == 3 and os.environ.get('SFEM_SORTED_SCATTER', '1') != '0':
+      return shared_slot_order(enc)
+    return None
 
   def _split_encoding(self):
     """`enc` with every node of the periodic / partition exchange flagged
@@ -444,7 +452,7 @@ class StokesDivGrad:
       other = torch.nonzero(mult != 1).reshape(-1)
       rng = (int(other.min()), int(other.max()) + 1) if other.numel() else (0, 0)
       enc = _ops.encode_elements(mesh.elements, self.dirichlet_u8, mult)
-      self._split = (enc, rng)
+      self._split = (enc, rng, self._order(mesh, enc))
     return self._split
 
   def e_apply(self, p, scale=None, exchange=None):
@@ -462,7 +470,7 @@ class StokesDivGrad:
                        f'{tuple(p.shape)}')
     from swirl_fem_amd.core import layout
     p = p.to(self.vspace.dtype).contiguous()
-    enc, zero_range = self._split_encoding()
+    enc, zero_range, order = self._split_encoding()
     w = layout.empty_component_major((mesh.num_nodes, mesh.ndim), p.dtype,
                                      p.device)
     if scale is not None:
@@ -472,7 +480,7 @@ class StokesDivGrad:
     out = torch.empty(self.num_pressure_nodes, dtype=p.dtype, device=p.device)
     args = (enc, self.penc, self.parts, self.host, mesh.ndim,
             mesh.gridpoints_1d.num_points)
-    _ops.stokes_e_first(p, w, out, *args, zero_range, scale)
+    _ops.stokes_e_first(p, w, out, *args, zero_range, scale, order)
     if exchange is not None:
       w = exchange(w)
     return _ops.stokes_e_second(w, out, *args, scale)
@@ -515,7 +523,8 @@ class StokesDivGrad:
         out = torch.empty(shape, dtype=p.dtype, device=p.device)
     return _ops.stokes_grad_t(p, out, self.enc, self.penc, self.parts,
                               self.host, mesh.ndim,
-                              mesh.gridpoints_1d.num_points, self.zero_range)
+                              mesh.gridpoints_1d.num_points, self.zero_range,
+                              self.shared_order)
 
 
 def _like_layout(t, ref):

@@ -406,6 +406,27 @@ struct ElemGeom {
   }
 };
 
+// Second half of the sorted shared scatter (see helmholtz_kernel): the lanes of
+// one element walk its SHARED slots in ascending node order; `vals` is the
+// padded element tensor in LDS, `codes` the element's `enc` row in slot order.
+template <typename T, int P, int DIM>
+__device__ __forceinline__ void scatter_shared_sorted(
+    const uint16_t* so, int stride, int t, const T* vals,
+    const uint32_t* codes, T* dst, int64_t ns) {
+  using Tile = HelmholtzTile<T, P, DIM>;
+  constexpr int TPE = Tile::TPE, SA = Tile::SA, SB = Tile::SB;
+  for (int q = t; q < stride; q += TPE) {
+    const uint32_t slot = so[q];
+    if (slot != 0xFFFFu) {
+      const uint32_t id = codes[slot] & SFEM_IDX_MASK;
+      const int a2 = slot / TPE, t2 = slot - a2 * TPE;
+      const int i2 = DIM == 3 ? t2 / P : 0;
+      const int j2 = DIM == 3 ? t2 - i2 * P : t2;
+      unsafeAtomicAdd(dst + (int64_t)id * ns, vals[a2 * SA + i2 * SB + j2]);
+    }
+  }
+}
+
 template <typename T, int P, int DIM, bool GS, bool SCALAR, int GM>
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
@@ -624,20 +645,10 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         }
       }
       __syncthreads();
-      if (active) {
-        const uint16_t* so = prm.shared_order + e * prm.shared_stride;
-        for (int q = t; q < prm.shared_stride; q += TPE) {
-          const uint32_t slot = so[q];
-          if (slot != 0xFFFFu) {
-            const uint32_t id = codes[slot] & SFEM_IDX_MASK;
-            const int a2 = slot / TPE, t2 = slot - a2 * TPE;
-            const int i2 = DIM == 3 ? t2 / P : 0;
-            const int j2 = DIM == 3 ? t2 - i2 * P : t2;
-            unsafeAtomicAdd(og + (int64_t)id * ns + k * ks,
-                            s0[a2 * SA + i2 * SB + j2]);
-          }
-        }
-      }
+      if (active)
+        scatter_shared_sorted<T, P, DIM>(
+            prm.shared_order + e * prm.shared_stride, prm.shared_stride, t, s0,
+            codes, og + k * ks, ns);
     }
 #pragma unroll
     for (int a = 0; a < P; ++a) {

@@ -45,6 +45,8 @@ struct StokesParams {
   int geo_mode;
   int64_t node_stride, comp_stride;
   int64_t scale_node_stride, scale_comp_stride;   // comp stride 0: one factor per node
+  const uint16_t* shared_order;   // as in HelmholtzParams, or null
+  int shared_stride;
 };
 
 // Pressure-basis values at the velocity points, by value in the kernel
@@ -473,23 +475,44 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
     T dt0[P];
     line_apply<T, P, true>(dm, w0, dt0);
     __syncthreads();
+    const bool sorted = prm.shared_order != nullptr;
 #pragma unroll
     for (int a = 0; a < P; ++a) {
       uint32_t ea = enc[a];
       asm volatile("" : "+v"(ea));
       const uint32_t id = ea & SFEM_IDX_MASK;
-      if (id != SFEM_IDX_PAD) {
-        const int o = a * SA + i * SB + j;
-        T v = dt0[a] + s0[o];
+      const int o = a * SA + i * SB + j;
+      T v = T(0);
+      if (lane_ok) {
+        v = dt0[a] + s0[o];
         if (DIM == 3) v += s1[o];
+      }
+      dt0[a] = v;
+      if (id != SFEM_IDX_PAD) {
         T* dst = prm.out + (int64_t)id * ns + c * ks;
         const bool dirichlet = ea & SFEM_IDX_DIRICHLET;
         if (ea & SFEM_IDX_SHARED) {
-          if (!dirichlet) unsafeAtomicAdd(dst, v);
+          if (!dirichlet && !sorted) unsafeAtomicAdd(dst, v);
         } else {
           *dst = dirichlet ? T(0) : v;
         }
       }
+    }
+    if (sorted) {   // shared slots in ascending node order (see helmholtz_kernel)
+      uint32_t* codes = reinterpret_cast<uint32_t*>(s1);
+      if (Tile::BLOCK > 64) __syncthreads();
+      if (lane_ok) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+          s0[a * SA + i * SB + j] = dt0[a];
+          codes[a * TPE + t] = enc[a];
+        }
+      }
+      __syncthreads();
+      if (active)
+        scatter_shared_sorted<T, P, DIM>(
+            prm.shared_order + e * prm.shared_stride, prm.shared_stride, t, s0,
+            codes, prm.out + c * ks, ns);
     }
     __syncthreads();
   }
@@ -616,12 +639,18 @@ stokes_e_first_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
       asm volatile("" : "+v"(ea));
       const uint32_t id = ea & SFEM_IDX_MASK;
       const int o = a * SA + i * SB + j;
-      T v = ua[a] + s0[o];
-      if (DIM == 3) v += s1[o];
+      T v = T(0);
+      if (lane_ok) {
+        v = ua[a] + s0[o];
+        if (DIM == 3) v += s1[o];
+      }
+      // (own position: staged for the sorted scatter of the shared slots)
+      if (prm.shared_order && lane_ok) s0[o] = v;
       ua[a] = T(0);
       if (id != SFEM_IDX_PAD && !(ea & SFEM_IDX_DIRICHLET)) {
         if (ea & SFEM_IDX_SHARED) {
-          unsafeAtomicAdd(prm.out + (int64_t)id * ns + c * ks, v);
+          if (!prm.shared_order)
+            unsafeAtomicAdd(prm.out + (int64_t)id * ns + c * ks, v);
         } else {
           if (prm.scale)
             v *= prm.scale[(int64_t)id * prm.scale_node_stride +
@@ -629,6 +658,19 @@ stokes_e_first_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
           ua[a] = v;
         }
       }
+    }
+    if (prm.shared_order) {
+      uint32_t* codes = reinterpret_cast<uint32_t*>(s1);
+      if (Tile::BLOCK > 64) __syncthreads();
+      if (lane_ok) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) codes[a * TPE + t] = enc[a];
+      }
+      __syncthreads();
+      if (active)
+        scatter_shared_sorted<T, P, DIM>(
+            prm.shared_order + e * prm.shared_stride, prm.shared_stride, t, s0,
+            codes, prm.out + c * ks, ns);
     }
     __syncthreads();
     // ---- D of the complete part, component c (stokes_div_kernel)

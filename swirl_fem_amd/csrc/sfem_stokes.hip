@@ -48,6 +48,8 @@ static int run_stokes(const sfem_stokes_args* a, int mode,
     prm.scale_node_stride = prm.node_stride;
     prm.scale_comp_stride = prm.comp_stride;
   }
+  prm.shared_order = a->shared_order;
+  prm.shared_stride = a->shared_stride;
   if (a->ndim == 3) return dispatch_stokes<T, 3>(prm, a->P, mode, stream);
   return dispatch_stokes<T, 2>(prm, a->P, mode, stream);
 }

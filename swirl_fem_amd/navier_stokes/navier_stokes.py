@@ -504,8 +504,11 @@ class StokesSEM:
                             else layout.component_major(q))
       # component-major intermediate: the shared-node atomics of one component
       # then hit whole lines (D^T 1.3 ms instead of 2.2 ms at 48^3, p = 7)
-      if op.penc is None and os.environ.get('SFEM_SPLIT_E', '1') != '0':
-        # nodes held by one element stay in registers between D^T and D
+      if op.penc is None and os.environ.get('SFEM_SPLIT_E', '0') == '1':
+        # opt-in: nodes held by one element stay in registers between D^T and
+        # D.  4 % faster than the two kernels below while their atomics ran in
+        # slot order; with the sorted shared scatter D^T alone dropped by a
+        # third and the plain pair wins (3.95 vs 4.71 ms at 64^3, p = 7)
         return op.e_apply(
             p, scale=self._cache[key],
             exchange=partial(self.velocity.exchange, inplace=True))

@@ -149,14 +149,15 @@ def test_split_pressure_operator_matches_oracle(ndim, n, P, dtype):
         assert relerr(got, two.double().cpu().numpy()) < tol
 
 
-def test_split_pressure_operator_with_periodic_images():
+def test_split_pressure_operator_with_periodic_images(monkeypatch):
   """Periodic images are complete only after the exchange: the split encoding
   flags them shared although one element holds each of them."""
+  monkeypatch.setenv('SFEM_SPLIT_E', '1')      # StokesSEM.E takes the split path
   for ndim, order in ((2, 5), (3, 4)):
     pm = unit_cube_mesh(3, ndim=ndim, periodic_dims=tuple(range(ndim)))
     sem = StokesSEM.create(pm, {}, order=order, device=DEV)
     op = sem._divgrad()
-    enc, rng = op._split_encoding()
+    enc, rng, _ = op._split_encoding()
     gi = sem.velocity.mesh.exchange_gather_indices.to(torch.int64)
     shared = torch.zeros(sem.velocity.mesh.num_nodes + 1, dtype=torch.bool,
                          device=DEV)
