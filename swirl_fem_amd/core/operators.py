@@ -187,6 +187,7 @@ class HelmholtzOperator:
       zero_range = ((int(unref.min()), int(unref.max()) + 1)
                     if unref.numel() else (0, 0))
     if (assembly != 'colored' and mesh.ndim == 3 and
+        mesh.gridpoints_1d.num_points <= 8 and      # one wave per element
         os.environ.get('SFEM_SORTED_SCATTER', '1') != '0'):
       # 3D: most slots of an element are shared; issue their atomics in node
       # order (better coalesced, see the kernel)
@@ -428,7 +429,8 @@ class StokesDivGrad:
 
   @staticmethod
   def _order(mesh, enc):
-    if mesh.ndim == 3 and os.environ.get('SFEM_SORTED_SCATTER', '1') != '0':
+    if (mesh.ndim == 3 and mesh.gridpoints_1d.num_points <= 8 and
+        os.environ.get('SFEM_SORTED_SCATTER', '1') != '0'):
       return shared_slot_order(enc)
     return None
 

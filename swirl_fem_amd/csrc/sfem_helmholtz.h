@@ -615,8 +615,13 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
       }
     }
     // direct-stiffness summation
-    const bool sorted = GS && prm.shared_order && !prm.colored;
-    if (sorted) {
+    // compiled in only when an element fits one wave: with several waves per
+    // element (P >= 9 in 3D) the extra barriers cost more than the coalescing
+    // gains (p = 11 fp32: 3.34 vs 3.16 ms), and even unused the code slowed
+    // those kernels down (2.31 -> 3.16 ms)
+    constexpr bool SORTABLE = GS && TPE <= 64;
+    const bool sorted = SORTABLE && prm.shared_order && !prm.colored;
+    if constexpr (SORTABLE) if (sorted) {
       // The atomics are bound by the number of memory-side requests, i.e. of
       // 64-byte lines an instruction touches.  In slot order an instruction
       // (fixed a, lanes (i, j)) meets 4 faces + 4 edges: ~3 lanes per line.
@@ -650,9 +655,9 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
             prm.shared_order + e * prm.shared_stride, prm.shared_stride, t, s0,
             codes, og + k * ks, ns);
     }
+    if (!sorted) {
 #pragma unroll
     for (int a = 0; a < P; ++a) {
-      if (sorted) break;
       if (GS) {
         uint32_t ea = enc[a];
         // keep the flag tests inside the component loop (hoisting them costs
@@ -675,6 +680,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
       } else if (active) {
         ol0[(int64_t)(slot_off + a * TPE) * ns + k * ks] = acc[a];
       }
+    }
     }
     if (k + 1 < nc) __syncthreads();
   }

@@ -475,7 +475,8 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
     T dt0[P];
     line_apply<T, P, true>(dm, w0, dt0);
     __syncthreads();
-    const bool sorted = prm.shared_order != nullptr;
+    constexpr bool SORTABLE = TPE <= 64;   // see helmholtz_kernel
+    const bool sorted = SORTABLE && prm.shared_order != nullptr;
 #pragma unroll
     for (int a = 0; a < P; ++a) {
       uint32_t ea = enc[a];
@@ -498,7 +499,7 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
         }
       }
     }
-    if (sorted) {   // shared slots in ascending node order (see helmholtz_kernel)
+    if constexpr (SORTABLE) if (sorted) {   // shared slots in ascending node order
       uint32_t* codes = reinterpret_cast<uint32_t*>(s1);
       if (Tile::BLOCK > 64) __syncthreads();
       if (lane_ok) {
@@ -645,11 +646,11 @@ stokes_e_first_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
         if (DIM == 3) v += s1[o];
       }
       // (own position: staged for the sorted scatter of the shared slots)
-      if (prm.shared_order && lane_ok) s0[o] = v;
+      if (TPE <= 64 && prm.shared_order && lane_ok) s0[o] = v;
       ua[a] = T(0);
       if (id != SFEM_IDX_PAD && !(ea & SFEM_IDX_DIRICHLET)) {
         if (ea & SFEM_IDX_SHARED) {
-          if (!prm.shared_order)
+          if (!(TPE <= 64 && prm.shared_order))
             unsafeAtomicAdd(prm.out + (int64_t)id * ns + c * ks, v);
         } else {
           if (prm.scale)
@@ -659,7 +660,7 @@ stokes_e_first_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
         }
       }
     }
-    if (prm.shared_order) {
+    if constexpr (TPE <= 64) if (prm.shared_order) {
       uint32_t* codes = reinterpret_cast<uint32_t*>(s1);
       if (Tile::BLOCK > 64) __syncthreads();
       if (lane_ok) {
