@@ -136,38 +136,6 @@ int sfem_stokes_div(const sfem_stokes_args* a, sfem_stream_t stream) {
   return run_stokes<float>(a, 0, as_stream(stream));
 }
 
-int sfem_stokes_grad_t(const sfem_stokes_args* a, sfem_stream_t stream) {
-  int rc = check_stokes("sfem_stokes_grad_t", a);
-  if (rc) return rc;
-  SFEM_REQUIRE(a->num_elements == 0 || (a->enc && a->interp),
-               "sfem_stokes_grad_t: null pointer");
-  SFEM_REQUIRE(a->zero_begin >= 0 && a->zero_end >= a->zero_begin &&
-                   a->zero_end <= a->num_nodes,
-               "sfem_stokes_grad_t: bad zero range");
-  const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
-  if (work == 0 && a->zero_end == a->zero_begin) return SFEM_OK;
-  SFEM_REQUIRE(a->out && (work == 0 || a->p_in),
-               "sfem_stokes_grad_t: null pointer");
-  const size_t sz = a->dtype == SFEM_F64 ? 8 : 4;
-  if (a->zero_end > a->zero_begin) {
-    // shared nodes are accumulated with atomics: clear their range first
-    const int64_t nstr = a->node_stride > 0 ? a->node_stride : a->ndim;
-    const int64_t cstr = a->node_stride > 0 ? a->comp_stride : 1;
-    const int rc0 =
-        cstr == 1
-            ? sfem_zero_strips((char*)a->out + a->zero_begin * nstr * sz,
-                               (a->zero_end - a->zero_begin) * nstr, 0, 1,
-                               a->dtype, stream)
-            : sfem_zero_strips((char*)a->out + a->zero_begin * nstr * sz,
-                               (a->zero_end - a->zero_begin) * nstr, cstr,
-                               a->ndim, a->dtype, stream);
-    if (rc0) return rc0;
-  }
-  if (work == 0) return SFEM_OK;
-  if (a->dtype == SFEM_F64) return run_stokes<double>(a, 1, as_stream(stream));
-  return run_stokes<float>(a, 1, as_stream(stream));
-}
-
 // zero-fill of the shared-node range of `out` (all components)
 static int zero_shared_range(const sfem_stokes_args* a, sfem_stream_t stream) {
   if (a->zero_end <= a->zero_begin) return SFEM_OK;
@@ -181,6 +149,26 @@ static int zero_shared_range(const sfem_stokes_args* a, sfem_stream_t stream) {
              : sfem_zero_strips((char*)a->out + a->zero_begin * nstr * sz,
                                 (a->zero_end - a->zero_begin) * nstr, cstr,
                                 a->ndim, a->dtype, stream);
+}
+
+int sfem_stokes_grad_t(const sfem_stokes_args* a, sfem_stream_t stream) {
+  int rc = check_stokes("sfem_stokes_grad_t", a);
+  if (rc) return rc;
+  SFEM_REQUIRE(a->num_elements == 0 || (a->enc && a->interp),
+               "sfem_stokes_grad_t: null pointer");
+  SFEM_REQUIRE(a->zero_begin >= 0 && a->zero_end >= a->zero_begin &&
+                   a->zero_end <= a->num_nodes,
+               "sfem_stokes_grad_t: bad zero range");
+  const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
+  if (work == 0 && a->zero_end == a->zero_begin) return SFEM_OK;
+  SFEM_REQUIRE(a->out && (work == 0 || a->p_in),
+               "sfem_stokes_grad_t: null pointer");
+  // shared nodes are accumulated with atomics: clear their range first
+  rc = zero_shared_range(a, stream);
+  if (rc) return rc;
+  if (work == 0) return SFEM_OK;
+  if (a->dtype == SFEM_F64) return run_stokes<double>(a, 1, as_stream(stream));
+  return run_stokes<float>(a, 1, as_stream(stream));
 }
 
 int sfem_stokes_e_first(const sfem_stokes_args* a, sfem_stream_t stream) {
