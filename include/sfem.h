@@ -317,6 +317,9 @@ typedef struct sfem_stokes_args {
   int32_t scale_per_node; /* scale is one (N,) factor shared by the components */
   const uint16_t* shared_order; /* grad_t / e_first: as in sfem_helmholtz_args, */
   int32_t shared_stride;        /*   or NULL                                    */
+  double* dot_out;        /* div: NULL, or SFEM_DOT_SLOTS device doubles that    */
+                          /*   accumulate partial sums of p_in . p_out (the p.Ap */
+                          /*   of the pressure CG when p_in is its direction)    */
 } sfem_stokes_args;
 
 int sfem_stokes_setup(const void* invjac, const void* jacdet,
@@ -389,11 +392,14 @@ int sfem_dot_indexed(const void* a, const void* b, const int64_t* idx,
                      double* result, int dtype, sfem_stream_t stream);
 /* out = w - (b . w / total) 1: the nullspace projection of the pressure
  * preconditioner (navier_stokes.py:73-78 with b = B 1, total = 1 . B 1).
- * Two launches, no atomics; `partials`: SFEM_DOT_SLOTS device doubles of
- * workspace (need not be cleared).  `out` may alias `w`.                     */
+ * Two launches; `partials`: SFEM_DOT_SLOTS device doubles of workspace (need
+ * not be cleared).  `out` may alias `w`.  `dot_result`: NULL, or one device
+ * double that accumulates w . out (the r . z of a CG preconditioned by this
+ * projection: its separate dot pass disappears).                             */
 int sfem_subtract_weighted_mean(const void* w, const void* b, double total,
                                 void* out, double* partials, int64_t count,
-                                int dtype, sfem_stream_t stream);
+                                double* dot_result, int dtype,
+                                sfem_stream_t stream);
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
                     double atol, double* partials, sfem_stream_t stream);
 int sfem_cg_update_xr(void* x, void* r, const void* p, const void* ap,

@@ -49,7 +49,7 @@ class StokesArgs(ctypes.Structure):
       ('P', c_i32), ('dtype', c_i32), ('geo_mode', c_i32),
       ('node_stride', c_i64), ('comp_stride', c_i64),
       ('scale_per_node', c_i32), ('shared_order', c_ptr),
-      ('shared_stride', c_i32),
+      ('shared_stride', c_i32), ('dot_out', c_ptr),
   ]
 
 
@@ -69,7 +69,7 @@ SIGNATURES = {
                               c_i32, c_ptr],
     'sfem_zero_strips': [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr],
     'sfem_subtract_weighted_mean': [c_ptr, c_ptr, c_dbl, c_ptr, c_ptr, c_i64,
-                                    c_i32, c_ptr],
+                                    c_ptr, c_i32, c_ptr],
     'sfem_pack': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     'sfem_unpack_add': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr],
     'sfem_pack_strided': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64,

@@ -199,8 +199,9 @@ def exchange_local_atomic(u, gather_indices, unique_indices):
   return out
 
 
-def subtract_weighted_mean(w, b, total, partials, out=None):
-  """out = w - (b . w / total) 1 (two launches, no host synchronisation)."""
+def subtract_weighted_mean(w, b, total, partials, out=None, dot_result=None):
+  """out = w - (b . w / total) 1 (two launches, no host synchronisation).
+  `dot_result = (scalars, slot)`: scalars[slot] += w . out as well."""
   w, b = w.contiguous(), b.contiguous()
   if w.shape != b.shape or w.dtype != b.dtype:
     raise ValueError('subtract_weighted_mean: operands differ in shape / dtype')
@@ -210,9 +211,16 @@ def subtract_weighted_mean(w, b, total, partials, out=None):
   if partials.dtype != torch.float64 or partials.numel() < _lib.SFEM_DOT_SLOTS:
     raise ValueError('partials: SFEM_DOT_SLOTS float64 values')
   with torch.cuda.device(dev):
+    dot_ptr = None
+    if dot_result is not None:
+      scalars, slot = dot_result
+      _dev(scalars)
+      if scalars.dtype != torch.float64:
+        raise ValueError('dot_result: float64 scalars')
+      dot_ptr = ctypes.c_void_p(scalars.data_ptr() + 8 * slot)
     _lib.check(_lib.load().sfem_subtract_weighted_mean(
         _ptr(w), _ptr(b), float(total), _ptr(out), _ptr(partials), w.numel(),
-        _dtype_code(w), _stream(dev)), 'sfem_subtract_weighted_mean')
+        dot_ptr, _dtype_code(w), _stream(dev)), 'sfem_subtract_weighted_mean')
   return out
 
 
@@ -477,9 +485,11 @@ def _check_field(u, ndim):
     raise ValueError(f'expected a dense (N, {ndim}) velocity field')
 
 
-def stokes_div(u, p_out, enc, penc, parts, host, ndim, P, scale=None):
+def stokes_div(u, p_out, enc, penc, parts, host, ndim, P, scale=None,
+               dot_with=None, dot_out=None):
   """p_out <- D(scale * u) (navier_stokes.py:313-333), one launch per
-  geometry kind."""
+  geometry kind.  `dot_out` (SFEM_DOT_SLOTS doubles) accumulates partial sums
+  of `dot_with . p_out`."""
   dev = _dev(enc, p_out)
   _check_field(u, ndim)
   per_node = scale is not None and scale.dim() == 1
@@ -497,7 +507,9 @@ def stokes_div(u, p_out, enc, penc, parts, host, ndim, P, scale=None):
     for part in parts:
       args = _stokes_args(u, enc, penc, part, host, ndim, P, (0, 0),
                           u=u.data_ptr(), p_out=p_out.data_ptr(),
-                          scale=_dptr(scale), scale_per_node=int(per_node))
+                          scale=_dptr(scale), scale_per_node=int(per_node),
+                          p_in=_dptr(dot_with if dot_out is not None else None),
+                          dot_out=_dptr(dot_out))
       _lib.check(_lib.load().sfem_stokes_div(ctypes.byref(args), _stream(dev)),
                  'sfem_stokes_div')
   return p_out

@@ -487,8 +487,9 @@ class StokesDivGrad:
       w = exchange(w)
     return _ops.stokes_e_second(w, out, *args, scale)
 
-  def div(self, u, scale=None, out=None):
-    """(N, d) -> (Np,):  D (scale * u); `scale` is (N, d) or (N,)."""
+  def div(self, u, scale=None, out=None, dot_with=None, dot_out=None):
+    """(N, d) -> (Np,):  D (scale * u); `scale` is (N, d) or (N,).
+    `dot_out`: SFEM_DOT_SLOTS doubles accumulating `dot_with . result`."""
     mesh = self.vspace.mesh
     if tuple(u.shape) != (mesh.num_nodes, mesh.ndim):
       raise ValueError(f'expected ({mesh.num_nodes}, {mesh.ndim}) velocity, '
@@ -506,8 +507,13 @@ class StokesDivGrad:
       # pressure nodes that no element references (none on refiner meshes)
       out = (torch.empty if self.penc is None else torch.zeros)(
           self.num_pressure_nodes, dtype=u.dtype, device=u.device)
+    if dot_out is not None:
+      dot_with = dot_with.to(u.dtype).contiguous()
+      if tuple(dot_with.shape) != (self.num_pressure_nodes,):
+        raise ValueError('dot_with must be a pressure vector')
     return _ops.stokes_div(u, out, self.enc, self.penc, self.parts, self.host,
-                           mesh.ndim, mesh.gridpoints_1d.num_points, scale)
+                           mesh.ndim, mesh.gridpoints_1d.num_points, scale,
+                           dot_with, dot_out)
 
   def grad_t(self, p, out=None, component_major=False):
     """(Np,) -> (N, d):  mask * D^T p."""

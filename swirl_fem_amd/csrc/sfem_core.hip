@@ -352,7 +352,7 @@ template <typename T>
 __global__ void __launch_bounds__(512)
 subtract_mean_kernel(const T* __restrict__ w, const double* __restrict__ partials,
                      int num_partials, double inv_total, T* __restrict__ out,
-                     int64_t count) {
+                     int64_t count, double* __restrict__ dot_result) {
   __shared__ double mean;
   double acc = 0.0;
   for (int i = threadIdx.x; i < num_partials; i += blockDim.x)
@@ -362,9 +362,17 @@ subtract_mean_kernel(const T* __restrict__ w, const double* __restrict__ partial
   __syncthreads();
   const T m = (T)mean;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double wz = 0.0;      // w . out: the r . z of a CG that uses this as M
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-       i += stride)
-    out[i] = w[i] - m;
+       i += stride) {
+    const T wi = w[i], zi = wi - m;
+    out[i] = zi;
+    wz += (double)wi * (double)zi;
+  }
+  if (dot_result) {
+    const double tot = block_sum(wz);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dot_result, tot);
+  }
 }
 
 // scalars (16 doubles): [0] gamma [1] p.Ap [2] gamma_new [3] alpha [4] beta
@@ -791,7 +799,8 @@ int sfem_zero_strips(void* base, int64_t strip_len, int64_t strip_stride,
 
 int sfem_subtract_weighted_mean(const void* w, const void* b, double total,
                                 void* out, double* partials, int64_t count,
-                                int dtype, sfem_stream_t stream) {
+                                double* dot_result, int dtype,
+                                sfem_stream_t stream) {
   SFEM_REQUIRE(count >= 0, "sfem_subtract_weighted_mean: bad count");
   SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
                "sfem_subtract_weighted_mean: unknown dtype %d", dtype);
@@ -806,9 +815,10 @@ int sfem_subtract_weighted_mean(const void* w, const void* b, double total,
                        0, as_stream(stream), (const T*)w, (const T*)b, count,
                        partials);
     hipLaunchKernelGGL(subtract_mean_kernel<T>,
-                       dim3(stream_grid(count, 512)), dim3(512), 0,
-                       as_stream(stream), (const T*)w, partials, (int)nblk,
-                       1.0 / total, (T*)out, count);
+                       dim3(dot_result ? reduce_grid(count, 512 * 4)
+                                       : stream_grid(count, 512)),
+                       dim3(512), 0, as_stream(stream), (const T*)w, partials,
+                       (int)nblk, 1.0 / total, (T*)out, count, dot_result);
   });
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;

@@ -47,6 +47,7 @@ struct StokesParams {
   int64_t scale_node_stride, scale_comp_stride;   // comp stride 0: one factor per node
   const uint16_t* shared_order;   // as in HelmholtzParams, or null
   int shared_stride;
+  double* dot_out;       // div: partial sums of p_in . p_out, or null
 };
 
 // Pressure-basis values at the velocity points, by value in the kernel
@@ -263,6 +264,7 @@ __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 stokes_div_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
   SFEM_STOKES_PROLOGUE;
+  double pdot = 0.0;     // this lane's share of p_in . p_out
   T tq[P];
 #pragma unroll
   for (int a = 0; a < P; ++a) tq[a] = T(0);
@@ -354,7 +356,11 @@ stokes_div_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
       for (int k = 0; k < PP; ++k) {
         const int slot = (i * PP + j) * PP + k;
         const int64_t pid = penc0 ? (int64_t)penc0[slot] : pbase + slot;
-        if (pid >= 0) prm.p_out[pid] = SECOND ? prm.p_out[pid] + y[k] : y[k];
+        if (pid >= 0) {
+          prm.p_out[pid] = SECOND ? prm.p_out[pid] + y[k] : y[k];
+          if (!SECOND && prm.dot_out)
+            pdot += (double)y[k] * (double)prm.p_in[pid];
+        }
       }
     }
   } else {
@@ -368,9 +374,21 @@ stokes_div_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
       for (int k = 0; k < PP; ++k) {
         const int slot = j * PP + k;
         const int64_t pid = penc0 ? (int64_t)penc0[slot] : pbase + slot;
-        if (pid >= 0) prm.p_out[pid] = SECOND ? prm.p_out[pid] + y[k] : y[k];
+        if (pid >= 0) {
+          prm.p_out[pid] = SECOND ? prm.p_out[pid] + y[k] : y[k];
+          if (!SECOND && prm.dot_out)
+            pdot += (double)y[k] * (double)prm.p_in[pid];
+        }
       }
     }
+  }
+  if (!SECOND && prm.dot_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pdot += __shfl_down(pdot, off, 64);
+    if ((tid & 63) == 0)
+      unsafeAtomicAdd(&prm.dot_out[(blockIdx.x * (Tile::BLOCK / 64) +
+                                    (tid >> 6)) & (SFEM_DOT_SLOTS - 1)],
+                      pdot);
   }
 }
 

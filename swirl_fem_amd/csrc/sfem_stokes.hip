@@ -50,6 +50,7 @@ static int run_stokes(const sfem_stokes_args* a, int mode,
   }
   prm.shared_order = a->shared_order;
   prm.shared_stride = a->shared_stride;
+  prm.dot_out = mode == 0 ? a->dot_out : nullptr;
   if (a->ndim == 3) return dispatch_stokes<T, 3>(prm, a->P, mode, stream);
   return dispatch_stokes<T, 2>(prm, a->P, mode, stream);
 }
@@ -132,6 +133,8 @@ int sfem_stokes_div(const sfem_stokes_args* a, sfem_stream_t stream) {
   const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
   if (work == 0) return SFEM_OK;
   SFEM_REQUIRE(a->u && a->p_out, "sfem_stokes_div: null pointer");
+  SFEM_REQUIRE(!a->dot_out || a->p_in,
+               "sfem_stokes_div: dot_out needs p_in (the vector to dot with)");
   if (a->dtype == SFEM_F64) return run_stokes<double>(a, 0, as_stream(stream));
   return run_stokes<float>(a, 0, as_stream(stream));
 }

@@ -180,8 +180,14 @@ class CGRunner:
       if reduce_fn is not None:
         reduce_fn(s.t[S.GAMMA_NEW:S.GAMMA_NEW + 1])
     else:
-      z = self.r if self.identity_m else M(self.r)
-      if dot_fn is None:
+      if (dot_fn is None and hasattr(M, 'apply_with_dot') and
+          isinstance(self.r, torch.Tensor)):
+        # the preconditioner accumulates r . M r itself (slot is zero here)
+        z = M.apply_with_dot(self.r, s.t, S.GAMMA_NEW)
+        if reduce_fn is not None:
+          reduce_fn(s.t[S.GAMMA_NEW:S.GAMMA_NEW + 1])
+      elif dot_fn is None:
+        z = self.r if self.identity_m else M(self.r)
         for xx, yy in zip(_leaves(self.r), _leaves(z)):
           _ops.dot(layout.flat(xx), layout.flat(layout.like(yy, xx)), s.t,
                    S.GAMMA_NEW, accumulate=True)
@@ -189,6 +195,7 @@ class CGRunner:
           reduce_fn(s.t[S.GAMMA_NEW:S.GAMMA_NEW + 1])
       else:
         # after convergence the done flag guards every consumer of this slot
+        z = self.r if self.identity_m else M(self.r)
         s.dot_into(S.GAMMA_NEW, self.r, z, dot_fn, reduce_fn)
     # x += alpha p rides with the p update (p is in registers there): 8 vector
     # passes per iteration instead of 9, same arithmetic

@@ -86,7 +86,45 @@ def _solve(differentiable, A, b, **kwargs):
   return x, info
 
 
-def _pressure_project_out_nullspace(sem, p):
+def _FUSED_DOTS():
+  # SFEM_FUSED_DOTS=0: the pressure CG computes its inner products itself
+  return os.environ.get('SFEM_FUSED_DOTS', '1') != '0'
+
+
+class _PressureOperator:
+  """`p -> E p` for `cg`, handing it p . E p from inside the `D` kernel."""
+
+  def __init__(self, sem, dt, time_order):
+    self.sem, self.dt, self.time_order = sem, dt, time_order
+    if (sem._divgrad() is not None and _FUSED_DOTS() and
+        os.environ.get('SFEM_SPLIT_E', '0') != '1'):
+      self.apply_with_dot = self._apply_with_dot
+
+  def __call__(self, p):
+    return self.sem.E(p, dt=self.dt, time_order=self.time_order)
+
+  def _apply_with_dot(self, p, partials):
+    return self.sem.E(p, dt=self.dt, time_order=self.time_order,
+                      dot_out=partials)
+
+
+class _NullspaceProjection:
+  """The default pressure preconditioner as an object `cg` can ask for
+  r . M r together with M r (one pass less per iteration)."""
+
+  def __init__(self, sem):
+    self.sem = sem
+    if not sem.is_partitioned and _FUSED_DOTS():
+      self.apply_with_dot = self._apply_with_dot
+
+  def __call__(self, p):
+    return _pressure_project_out_nullspace(self.sem, p)
+
+  def _apply_with_dot(self, r, scalars, slot):
+    return _pressure_project_out_nullspace(self.sem, r, (scalars, slot))
+
+
+def _pressure_project_out_nullspace(sem, p, dot_result=None):
   """Remove the nullspace (all 1s vector) from p."""
   w = sem.pressure.exchange(p)
   # The reference applies the pressure mass matrix twice per call,
@@ -104,7 +142,8 @@ def _pressure_project_out_nullspace(sem, p):
           torch.empty(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
                       device=p.device), float(total))
     partials, total_host = sem._cache['project_partials']
-    return _ops.subtract_weighted_mean(w, b1, total_host, partials)
+    return _ops.subtract_weighted_mean(w, b1, total_host, partials,
+                                       dot_result=dot_result)
   return w - sem._global_sum(torch.vdot(b1, w).reshape(1)) / total
 
 
@@ -485,8 +524,9 @@ class StokesSEM:
     beta_k = bdfk_coeffs(time_order)[-1]
     return (dt / beta_k) * self.Bi(u)
 
-  def E(self, p, dt: float, time_order: int):
-    """Apply the operator E = D Q D^T."""
+  def E(self, p, dt: float, time_order: int, dot_out=None):
+    """Apply the operator E = D Q D^T.  `dot_out`: SFEM_DOT_SLOTS device
+    doubles that accumulate partial sums of p . E p (for `cg`)."""
     op = None if autodiff.needs_grad(p) else self._divgrad()
     if op is not None:
       # two kernels: D^T, then D with Q = (dt / beta_k) diag(QQ^T B)^-1 folded
@@ -509,12 +549,16 @@ class StokesSEM:
         # D.  4 % faster than the two kernels below while their atomics ran in
         # slot order; with the sorted shared scatter D^T alone dropped by a
         # third and the plain pair wins (3.95 vs 4.71 ms at 64^3, p = 7)
+        if dot_out is not None:
+          raise NotImplementedError('fused p . E p with the split E')
         return op.e_apply(
             p, scale=self._cache[key],
             exchange=partial(self.velocity.exchange, inplace=True))
       w = self.velocity.exchange(op.grad_t(p, component_major=True),
                                  inplace=True)
-      return op.div(w, scale=self._cache[key])
+      return op.div(w, scale=self._cache[key], dot_with=p, dot_out=dot_out)
+    if dot_out is not None:
+      raise NotImplementedError('fused p . E p needs the fused Stokes kernels')
     return self.D(self.Q(self.Dt(p), dt=dt, time_order=time_order))
 
   # ------------------------------------------------------------- time stepping
@@ -526,7 +570,7 @@ class StokesSEM:
                       atol: float = 0) -> tuple[torch.Tensor, torch.Tensor, Any]:
     """Evolves the Stokes system by one fractional step (reference :350-458)."""
     if pressure_preconditioner is None and project_out_nullspace:
-      pressure_preconditioner = partial(_pressure_project_out_nullspace, self)
+      pressure_preconditioner = _NullspaceProjection(self)
 
     ext_coeffs = extk_coeffs(k=1)
     p_ext = sum(float(ext_coeffs[-i]) * ps[-i]
@@ -564,7 +608,7 @@ class StokesSEM:
 
     u_star = self.filter(u_star, alpha=alpha)
 
-    dp, info = _solve(diff, partial(self.E, dt=dt, time_order=time_order),
+    dp, info = _solve(diff, _PressureOperator(self, dt, time_order),
                       -self.D(u_star), M=pressure_preconditioner, tol=tol,
                       atol=atol, graph=graph, reduce_fn=self._reduce_fn())
     aux['dp_info'] = info

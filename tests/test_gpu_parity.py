@@ -195,6 +195,15 @@ def test_subtract_weighted_mean(dtype, n):
   assert relerr(out.double(), want.cpu().numpy()) < TOL[dtype]
   assert abs(float(torch.dot(b.double(), out.double())) / total) < (
       1e-12 if dtype == torch.float64 else 1e-5)
+  # ... and w . out on the side (the r . z of the pressure CG)
+  scal = torch.zeros(16, dtype=torch.float64, device=DEV)
+  scal[3] = 2.5
+  out2 = _ops.subtract_weighted_mean(w, b, total, partials,
+                                     dot_result=(scal, 3))
+  assert torch.equal(out2, out)
+  wz = float(torch.dot(w.double(), out.double()))
+  assert abs(float(scal[3]) - 2.5 - wz) < (1e-11 if dtype == torch.float64
+                                           else 1e-4) * max(abs(wz), 1.0)
   assert _ops.subtract_weighted_mean(w, b, total, partials, out=w) is w
   assert relerr(w.double(), want.cpu().numpy()) < TOL[dtype]
 

@@ -149,6 +149,39 @@ def test_split_pressure_operator_matches_oracle(ndim, n, P, dtype):
         assert relerr(got, two.double().cpu().numpy()) < tol
 
 
+@pytest.mark.parametrize('ndim,order', [(2, 5), (3, 4), (3, 7)])
+def test_pressure_cg_gets_its_dots_from_the_kernels(ndim, order):
+  """p . E p comes out of the `D` kernel and r . M r out of the projection
+  kernel: same numbers as separate dot products, same solve."""
+  from swirl_fem_amd import _lib
+  from swirl_fem_amd.linalg.cg import cg
+  from swirl_fem_amd.navier_stokes import navier_stokes as ns
+  pm = unit_cube_mesh(2 if order == 7 else 3, ndim=ndim,
+                      periodic_dims=tuple(range(ndim)))
+  sem = StokesSEM.create(pm, {}, order=order, device=DEV)
+  g = torch.Generator(device=DEV).manual_seed(2)
+  Np = sem.pressure.pspace.mesh.num_nodes
+  p = torch.randn(Np, dtype=torch.float64, device=DEV, generator=g)
+  E = ns._PressureOperator(sem, 1e-2, 2)
+  M = ns._NullspaceProjection(sem)
+  partials = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64, device=DEV)
+  Ep = E.apply_with_dot(p, partials)
+  assert float((Ep - E(p)).abs().max()) < 1e-13 * float(Ep.abs().max())
+  want = float(torch.dot(p, Ep))
+  assert abs(float(partials.sum()) - want) < 1e-12 * abs(want)
+  scal = torch.zeros(16, dtype=torch.float64, device=DEV)
+  z = M.apply_with_dot(p, scal, 2)
+  assert torch.equal(z, M(p))
+  want = float(torch.dot(p, z))
+  assert abs(float(scal[2]) - want) < 1e-12 * abs(want)
+  # the solve with the fused dots equals the solve with plain callables
+  b = E(torch.randn(Np, dtype=torch.float64, device=DEV, generator=g))
+  x1, i1 = cg(E, b, M=M, tol=1e-10, maxiter=500)
+  x2, i2 = cg(lambda q: E(q), b, M=lambda r: M(r), tol=1e-10, maxiter=500)
+  assert i1['num_iterations'] == i2['num_iterations']
+  assert float((x1 - x2).abs().max()) < 1e-9 * float(x2.abs().max())
+
+
 def test_split_pressure_operator_with_periodic_images(monkeypatch):
   """Periodic images are complete only after the exchange: the split encoding
   flags them shared although one element holds each of them."""
