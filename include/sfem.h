@@ -369,6 +369,7 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *                      phase 0 = after p.Ap, phase 1 = end of iteration,
  *                      phase 3 = p.Ap <- sum of the SFEM_DOT_SLOTS partial
  *                      sums written by sfem_helmholtz_apply (`partials`);
+ *                      phase 4 = phase 3 then phase 0 in one launch;
  *                      phases 1 and 2 clear `partials` when it is given
  * sfem_cg_update_xr:   x += alpha p; r -= alpha Ap;  (cg.py:80-81)
  *                      fuse_rr != 0 also accumulates gamma_new += r.r (M = I)

@@ -573,6 +573,8 @@ static void launch_update_r(bool fuse_rr, bool nt, int grid, hipStream_t stream,
 //     atol2 = max(tol^2 b.b, atol^2); clear pAp, iterations;
 //     done <- !(gamma0 > atol2) or maxiter <= 0          (cg.py:65-73)
 // phase 0 (p.Ap accumulated in [1]): alpha = gamma / pAp; clear gamma_new
+// phase 3: p.Ap <- sum of the partial sums an operator left in `partials`;
+// phase 4 = phase 3 + phase 0 in one launch (no all-reduce in between)
 // phase 1 (gamma_new accumulated in [2]): beta = gamma_new / gamma;
 //     gamma <- gamma_new; clear pAp; ++iterations;
 //     done <- !(gamma > atol2) or iterations >= maxiter   (cg.py:68-73)
@@ -580,11 +582,17 @@ __global__ void __launch_bounds__(256)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
                  double atol, double* partials) {
   const int tid = threadIdx.x;
-  if (phase == 3) {           // p.Ap <- sum of the fused partial sums
+  if (phase == 3 || phase == 4) {   // p.Ap <- sum of the fused partial sums
     double v = 0.0;
     for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) v += partials[q];
     const double total = block_sum(v);
-    if (tid == 0 && scalars[7] == 0.0) scalars[1] = total;
+    if (tid == 0 && scalars[7] == 0.0) {
+      scalars[1] = total;
+      if (phase == 4) {             // ... and phase 0 in the same launch
+        scalars[3] = scalars[0] / total;
+        scalars[2] = 0.0;
+      }
+    }
     return;
   }
   if (partials && (phase == 1 || phase == 2))
@@ -982,7 +990,7 @@ int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
 
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
                     double atol, double* partials, sfem_stream_t stream) {
-  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 3 && (phase != 3 || partials),
+  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 4 && (phase < 3 || partials),
                "sfem_cg_scalars: bad arguments");
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
                      as_stream(stream), scalars, phase, maxiter, tol, atol,

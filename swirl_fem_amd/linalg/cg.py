@@ -149,9 +149,12 @@ class CGRunner:
     s, S = self.s, _Scalars
     A, M, dot_fn, reduce_fn = self.A, self.M, self.dot_fn, self.reduce_fn
     args = (self.maxiter, self.tol, self.atol, self.parts)
+    merged = self.fused_dot and reduce_fn is None
     if self.fused_dot:
       Ap = A.apply_with_dot(self.p, s.partials)
-      _ops.cg_scalars(s.t, 3, *args)
+      # one scalar launch when nothing (an all-reduce) sits between the sum
+      # of the partials and alpha
+      _ops.cg_scalars(s.t, 4 if merged else 3, *args)
       if reduce_fn is not None:
         reduce_fn(s.t[S.PAP:S.PAP + 1])
     else:
@@ -169,7 +172,8 @@ class CGRunner:
         reduce_fn(s.t[S.PAP:S.PAP + 1])
     else:
       s.dot_into(S.PAP, self.p, Ap, dot_fn, reduce_fn)
-    _ops.cg_scalars(s.t, 0, *args)
+    if not merged:
+      _ops.cg_scalars(s.t, 0, *args)
     for rr, aa in zip(_leaves(self.r), _leaves(Ap)):
       _ops.cg_update_r(layout.flat(rr), layout.flat(layout.like(aa, rr)), s.t,
                        self.fuse_rr)
