@@ -358,7 +358,7 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  * SFEM_CG_NSCALARS doubles:
  *   [0] gamma = r.M r   [1] p.Ap   [2] gamma_new   [3] alpha   [4] beta
  *   [5] b.b   [6] atol2 = max(tol^2 b.b, atol^2)   [7] done (0/1)
- *   [8] iterations
+ *   [8] iterations   [9] an iteration is open (phases 5 / 6)
  * Once `done` is set every kernel below is a no-op, so the host may run ahead
  * and poll [7] asynchronously; the iterate and the iteration count are exactly
  * those of a loop that tests the condition of cg.py:68-73 every iteration.
@@ -370,6 +370,13 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *                      phase 3 = p.Ap <- sum of the SFEM_DOT_SLOTS partial
  *                      sums written by sfem_helmholtz_apply (`partials`);
  *                      phase 4 = phase 3 then phase 0 in one launch;
+ *                      phase 5 = [close the previous iteration as phase 1
+ *                      would, if one is open: scalars[9]] then phase 4, and
+ *                      `partials` is cleared at once: ONE scalar launch per
+ *                      iteration, placed between the apply and the updates;
+ *                      the done flag is then raised one (harmless) apply
+ *                      late; phase 6 = close the open iteration now (before
+ *                      the host reads [0], [7] or [8]);
  *                      phases 1 and 2 clear `partials` when it is given
  * sfem_cg_update_xr:   x += alpha p; r -= alpha Ap;  (cg.py:80-81)
  *                      fuse_rr != 0 also accumulates gamma_new += r.r (M = I)

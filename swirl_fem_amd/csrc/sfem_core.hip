@@ -575,6 +575,7 @@ static void launch_update_r(bool fuse_rr, bool nt, int grid, hipStream_t stream,
 // phase 0 (p.Ap accumulated in [1]): alpha = gamma / pAp; clear gamma_new
 // phase 3: p.Ap <- sum of the partial sums an operator left in `partials`;
 // phase 4 = phase 3 + phase 0 in one launch (no all-reduce in between)
+// phase 5 / 6: see the kernel (one scalar launch per iteration)
 // phase 1 (gamma_new accumulated in [2]): beta = gamma_new / gamma;
 //     gamma <- gamma_new; clear pAp; ++iterations;
 //     done <- !(gamma > atol2) or iterations >= maxiter   (cg.py:68-73)
@@ -582,6 +583,40 @@ __global__ void __launch_bounds__(256)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
                  double atol, double* partials) {
   const int tid = threadIdx.x;
+  if (phase == 5 || phase == 6) {
+    // Deferred bookkeeping: phase 5 sits between the apply and the updates
+    // of iteration k+1 and first closes iteration k (what phase 1 does), so
+    // an iteration needs one scalar launch.  The convergence flag is then
+    // raised one apply late -- that apply only writes scratch -- and phase 6
+    // closes the open iteration when the host wants to look ([9] = open).
+    double total = 0.0;
+    if (phase == 5) {
+      double v = 0.0;
+      for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) {
+        v += partials[q];
+        partials[q] = 0.0;          // the next apply accumulates again
+      }
+      total = block_sum(v);
+    }
+    if (tid != 0 || scalars[7] != 0.0) return;
+    if (scalars[9] != 0.0) {
+      scalars[4] = scalars[2] / scalars[0];
+      scalars[0] = scalars[2];
+      scalars[8] += 1.0;
+      scalars[9] = 0.0;
+      if (!(scalars[0] > scalars[6]) || scalars[8] >= maxiter) {
+        scalars[7] = 1.0;
+        return;
+      }
+    }
+    if (phase == 5) {
+      scalars[1] = total;
+      scalars[3] = scalars[0] / total;
+      scalars[2] = 0.0;
+      scalars[9] = 1.0;
+    }
+    return;
+  }
   if (phase == 3 || phase == 4) {   // p.Ap <- sum of the fused partial sums
     double v = 0.0;
     for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) v += partials[q];
@@ -990,7 +1025,8 @@ int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
 
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
                     double atol, double* partials, sfem_stream_t stream) {
-  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 4 && (phase < 3 || partials),
+  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 6 &&
+                   (phase < 3 || phase == 6 || partials),
                "sfem_cg_scalars: bad arguments");
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
                      as_stream(stream), scalars, phase, maxiter, tol, atol,

@@ -152,9 +152,10 @@ class CGRunner:
     merged = self.fused_dot and reduce_fn is None
     if self.fused_dot:
       Ap = A.apply_with_dot(self.p, s.partials)
-      # one scalar launch when nothing (an all-reduce) sits between the sum
-      # of the partials and alpha
-      _ops.cg_scalars(s.t, 4 if merged else 3, *args)
+      # Without an all-reduce between the sum of the partials and alpha the
+      # iteration needs ONE scalar launch: phase 5 also closes the previous
+      # iteration (beta, gamma, counter, convergence flag) -- see `_flush`.
+      _ops.cg_scalars(s.t, 5 if merged else 3, *args)
       if reduce_fn is not None:
         reduce_fn(s.t[S.PAP:S.PAP + 1])
     else:
@@ -206,7 +207,8 @@ class CGRunner:
     for xx, pp, zz in zip(_leaves(self.x), _leaves(self.p), _leaves(z)):
       _ops.cg_update_xp(layout.flat(xx), layout.flat(pp),
                         layout.flat(layout.like(zz, pp)), s.t)
-    _ops.cg_scalars(s.t, 1, *args)
+    if not merged:
+      _ops.cg_scalars(s.t, 1, *args)
     self.issued += 1
 
   def capture(self) -> bool:
@@ -239,11 +241,19 @@ class CGRunner:
     self._graph = graph
     return True
 
+  def _flush(self):
+    """Closes the iteration that the single-scalar-launch scheme leaves open
+    (no-op otherwise), so that the scalars describe the last `step()`."""
+    if self.fused_dot and self.reduce_fn is None:
+      _ops.cg_scalars(self.s.t, 6, self.maxiter, self.tol, self.atol, None)
+
   def done(self) -> bool:
     """Synchronising poll of the device convergence flag."""
+    self._flush()
     return bool(self.s.t[_Scalars.DONE].item() != 0.0)
 
   def info(self):
+    self._flush()
     scal = self.s.t.cpu()
     return {'residual': self.s.t[_Scalars.GAMMA].clone(),
             'num_iterations': int(scal[_Scalars.ITERS].item())}

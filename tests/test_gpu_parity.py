@@ -831,6 +831,39 @@ def test_cg_graph_replay_matches_eager():
   assert float((x3 - x2).abs().max()) < 1e-12 * float(x3.abs().max())
 
 
+def test_cg_single_scalar_launch_matches_the_three_phase_sequence():
+  """With a fused p.Ap and no all-reduce an iteration has ONE scalar launch
+  (phase 5: closes the previous iteration, then alpha); the bookkeeping seen
+  by the host (`info`, `done`) must equal the three-phase sequence step by
+  step, including the step at which convergence is flagged and maxiter."""
+  from swirl_fem_amd.linalg.cg import CGRunner
+  rp = make_case(2, 4, 5, jitter=0.1, seed=5)          # 2D: deterministic sums
+  mesh, fes, _ = spaces(rp, 5, 5, 'gll')
+  bm = mesh.physical_masks['boundary']
+  op = fes.helmholtz_operator(bm, assembly='colored')   # bitwise reproducible
+  b = dev(np.random.default_rng(3).standard_normal(mesh.num_nodes)) * (~bm)
+  A = op.linear_operator(0.3, 1.0)
+  for maxiter in (10 ** 6, 7):
+    one = CGRunner(A, b, tol=1e-9, maxiter=maxiter)
+    three = CGRunner(A, b, tol=1e-9, maxiter=maxiter, reduce_fn=lambda t: t)
+    assert one.fused_dot and three.fused_dot
+    for step in range(200):
+      one.step(); three.step()
+      if step % 3 == 0 or step > 40:                    # polls interleave
+        i1, i3 = one.info(), three.info()
+        assert i1['num_iterations'] == i3['num_iterations']
+        assert abs(float(i1['residual']) - float(i3['residual'])) <= 1e-13 * abs(
+            float(i3['residual']))
+        assert one.done() == three.done()
+      if one.done() and three.done():
+        break
+    assert one.done() and three.done()
+    assert one.info()['num_iterations'] == three.info()['num_iterations'] == (
+        7 if maxiter == 7 else one.info()['num_iterations'])
+    assert float((one.x - three.x).abs().max()) <= 1e-13 * float(
+        three.x.abs().max())
+
+
 def test_poisson_config1_matches_oracle_and_series():
   """BASELINE config 1: 2D Poisson, 16x16 quads on [-1,1]^2, p=3."""
   from swirl_fem_amd.examples.poisson import BCType, solve_poisson

@@ -178,8 +178,9 @@ def test_pressure_cg_gets_its_dots_from_the_kernels(ndim, order):
   b = E(torch.randn(Np, dtype=torch.float64, device=DEV, generator=g))
   x1, i1 = cg(E, b, M=M, tol=1e-10, maxiter=500)
   x2, i2 = cg(lambda q: E(q), b, M=lambda r: M(r), tol=1e-10, maxiter=500)
-  assert i1['num_iterations'] == i2['num_iterations']
-  assert float((x1 - x2).abs().max()) < 1e-9 * float(x2.abs().max())
+  # (atomic summation order differs between the runs: the count may tip by one)
+  assert abs(i1['num_iterations'] - i2['num_iterations']) <= 1
+  assert float((x1 - x2).abs().max()) < 1e-8 * float(x2.abs().max())
 
 
 def test_split_pressure_operator_with_periodic_images(monkeypatch):
