@@ -280,7 +280,11 @@ int sfem_helmholtz_local(const sfem_helmholtz_args* args, sfem_stream_t stream);
  *   sfem_stokes_grad_t:  out = mask * velocity.scatter(Dt_local(pressure.gather(p)))
  *       Dt_local(p)_{i,c} = sum_q w_q detJ_q p(x_q) d phi_i/d x_c      (:322-338)
  *       DIRICHLET / SHARED bits of `enc` as in sfem_helmholtz_apply; the shared
- *       range [zero_begin, zero_end) of `out` is cleared by the call.
+ *       range [zero_begin, zero_end) of `out` is cleared by the call.  `scale`
+ *       (optional, as for div) multiplies every element's contribution before it
+ *       is assembled: for a factor that is equal on all copies of a node this
+ *       is scale * (D^T p) after QQ^T, and E = D QQ^T (Q . D^T) spares D the
+ *       gather of Q.
  *
  * Both integrate on the velocity GLL points (the `quadrature` of :279-282).
  * Geometry: SFEM_GEO_AFFINE / SFEM_GEO_MULTILINEAR evaluate the cofactors of

@@ -516,16 +516,20 @@ def stokes_div(u, p_out, enc, penc, parts, host, ndim, P, scale=None,
 
 
 def stokes_grad_t(p, out, enc, penc, parts, host, ndim, P, zero_range,
-                  shared_order=None):
-  """out <- mask * D^T p (navier_stokes.py:322-338)."""
+                  shared_order=None, scale=None):
+  """out <- mask * QQ^T-ready (scale * D^T p) (navier_stokes.py:322-338);
+  `scale`: (N,) or field-shaped factor applied to every contribution before
+  it is assembled (valid for factors equal on all copies of a node)."""
   dev = _dev(enc, p)
   _check_field(out, ndim)
+  per_node = _scale_args(scale, out, ndim)
   host = {k: _host(v, out.dtype) for k, v in host.items()}
   with torch.cuda.device(dev):
     for n, part in enumerate(parts):
       args = _stokes_args(out, enc, penc, part, host, ndim, P,
                           zero_range if n == 0 else (0, 0), shared_order,
-                          out=out.data_ptr(), p_in=p.data_ptr())
+                          out=out.data_ptr(), p_in=p.data_ptr(),
+                          scale=_dptr(scale), scale_per_node=int(per_node))
       _lib.check(_lib.load().sfem_stokes_grad_t(ctypes.byref(args),
                                                 _stream(dev)),
                  'sfem_stokes_grad_t')

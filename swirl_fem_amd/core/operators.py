@@ -515,8 +515,10 @@ class StokesDivGrad:
                            mesh.ndim, mesh.gridpoints_1d.num_points, scale,
                            dot_with, dot_out)
 
-  def grad_t(self, p, out=None, component_major=False):
-    """(Np,) -> (N, d):  mask * D^T p."""
+  def grad_t(self, p, out=None, component_major=False, scale=None):
+    """(Np,) -> (N, d):  mask * (scale * D^T p), the factor applied to every
+    element's contribution before assembly (it must be equal on all copies
+    of a node; then it commutes with the direct-stiffness sum and QQ^T)."""
     mesh = self.vspace.mesh
     if tuple(p.shape) != (self.num_pressure_nodes,):
       raise ValueError(f'expected ({self.num_pressure_nodes},) pressure, got '
@@ -529,10 +531,14 @@ class StokesDivGrad:
         out = layout.empty_component_major(shape, p.dtype, p.device)
       else:
         out = torch.empty(shape, dtype=p.dtype, device=p.device)
+    if scale is not None:
+      scale = scale.to(p.dtype)
+      scale = (scale.contiguous() if scale.dim() == 1
+               else _like_layout(scale.expand_as(out), out))
     return _ops.stokes_grad_t(p, out, self.enc, self.penc, self.parts,
                               self.host, mesh.ndim,
                               mesh.gridpoints_1d.num_points, self.zero_range,
-                              self.shared_order)
+                              self.shared_order, scale)
 
 
 def _like_layout(t, ref):

@@ -506,6 +506,11 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
         v = dt0[a] + s0[o];
         if (DIM == 3) v += s1[o];
       }
+      // a diagonal factor that is the same on every copy of a node commutes
+      // with the assembly: E = D QQ^T (Q . D^T) saves the gather of Q in D
+      if (prm.scale && id != SFEM_IDX_PAD)
+        v *= prm.scale[(int64_t)id * prm.scale_node_stride +
+                       c * prm.scale_comp_stride];
       dt0[a] = v;
       if (id != SFEM_IDX_PAD) {
         T* dst = prm.out + (int64_t)id * ns + c * ks;

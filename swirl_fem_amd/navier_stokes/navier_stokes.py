@@ -554,9 +554,13 @@ class StokesSEM:
         return op.e_apply(
             p, scale=self._cache[key],
             exchange=partial(self.velocity.exchange, inplace=True))
-      w = self.velocity.exchange(op.grad_t(p, component_major=True),
-                                 inplace=True)
-      return op.div(w, scale=self._cache[key], dot_with=p, dot_out=dot_out)
+      # Q is the same on every copy of a node, so it commutes with the
+      # assembly and the exchange: applied inside D^T (whose scatter waits on
+      # atomics anyway) it spares D one gather per node
+      w = self.velocity.exchange(
+          op.grad_t(p, component_major=True, scale=self._cache[key]),
+          inplace=True)
+      return op.div(w, dot_with=p, dot_out=dot_out)
     if dot_out is not None:
       raise NotImplementedError('fused p . E p needs the fused Stokes kernels')
     return self.D(self.Q(self.Dt(p), dt=dt, time_order=time_order))

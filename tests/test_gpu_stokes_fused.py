@@ -103,6 +103,11 @@ def test_div_and_grad_t_match_oracle(ndim, n, P, dtype):
       d1_ref = op.scatter(O.div_local(ov, op, ov.gather(s1[:, None] * u)))
       assert relerr(fused.div(ud, scale=dev(s1, dtype)), d1_ref) < tol
       assert relerr(fused.grad_t(pd), g_ref) < tol, (geometry, shear)
+      # per-node factor applied to the contributions before assembly
+      assert relerr(fused.grad_t(pd, scale=dev(s1, dtype)),
+                    s1[:, None] * g_ref) < tol
+      assert relerr(fused.grad_t(pd, scale=dev(sc, dtype),
+                                 component_major=True), sc * g_ref) < tol
       # component-major storage of the velocity-sized fields
       ucm = layout.component_major(ud)
       assert relerr(fused.div(ucm, scale=dev(sc, dtype)), ds_ref) < tol
