@@ -427,7 +427,10 @@ __device__ __forceinline__ void scatter_shared_sorted(
   }
 }
 
-template <typename T, int P, int DIM, bool GS, bool SCALAR, int GM>
+// SORTED: the sorted shared scatter below, its own instantiation (compiled
+// together with the slot-order scatter it cost registers in both).
+template <typename T, int P, int DIM, bool GS, bool SCALAR, int GM,
+          bool SORTED = false>
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
@@ -615,13 +618,13 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
       }
     }
     // direct-stiffness summation
-    // compiled in only when an element fits one wave: with several waves per
-    // element (P >= 9 in 3D) the extra barriers cost more than the coalescing
-    // gains (p = 11 fp32: 3.34 vs 3.16 ms), and even unused the code slowed
-    // those kernels down (2.31 -> 3.16 ms)
-    constexpr bool SORTABLE = GS && TPE <= 64;
-    const bool sorted = SORTABLE && prm.shared_order && !prm.colored;
-    if constexpr (SORTABLE) if (sorted) {
+    // SORTED is instantiated for one-wave elements in 3D only (see
+    // launch_helmholtz): with several waves per element (P >= 9) the extra
+    // barriers cost more than the coalescing gains (p = 11 fp32: 3.34 vs
+    // 3.16 ms), and compiled into the same kernel as the slot-order scatter
+    // the code slowed both down (p = 11: 2.31 -> 3.16 ms)
+    constexpr bool sorted = GS && SORTED;
+    if constexpr (sorted) {
       // The atomics are bound by the number of memory-side requests, i.e. of
       // 64-byte lines an instruction touches.  In slot order an instruction
       // (fixed a, lanes (i, j)) meets 4 faces + 4 edges: ~3 lanes per line.
@@ -707,9 +710,21 @@ int launch_helmholtz(const HelmholtzParams<T>& prm, hipStream_t stream) {
   const DMat<T, P> dm =
       make_dmat<T, P>(prm.dmat_host, prm.weights_host, prm.nodes_host);
   const dim3 grid((unsigned)groups), block(Tile::BLOCK);
+  // One-wave elements in 3D can issue their atomics in node order.  Not the
+  // multilinear kernels: they sit at the 128-VGPR budget of 4 waves per SIMD
+  // and the sorted path spills (1.09 vs 1.04 ms; 1.13 ms with 3 waves).
+  constexpr bool CAN_SORT = GS && DIM == 3 && Tile::TPE <= 64;
+  const bool sorted = CAN_SORT && prm.shared_order && !prm.colored;
 #define SFEM_LAUNCH_GM(SC, GMV, PRM)                                          \
-  hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, SC, GMV>), grid, block, \
-                     0, stream, PRM, dm)
+  do {                                                                        \
+    constexpr bool SORT_GM = CAN_SORT && GMV != GEO_MULTILINEAR;              \
+    if (sorted && SORT_GM)                                                    \
+      hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, SC, GMV, SORT_GM>), \
+                         grid, block, 0, stream, PRM, dm);                    \
+    else                                                                      \
+      hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, SC, GMV, false>),   \
+                         grid, block, 0, stream, PRM, dm);                    \
+  } while (0)
   if (prm.ncomp == 1) {
     switch (prm.geo_mode) {
       case GEO_POINT: SFEM_LAUNCH_GM(true, GEO_POINT, prm); break;

@@ -392,7 +392,7 @@ stokes_div_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
   }
 }
 
-template <typename T, int P, int PP, int DIM, int GM>
+template <typename T, int P, int PP, int DIM, int GM, bool SORTED = false>
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
@@ -493,8 +493,7 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
     T dt0[P];
     line_apply<T, P, true>(dm, w0, dt0);
     __syncthreads();
-    constexpr bool SORTABLE = TPE <= 64;   // see helmholtz_kernel
-    const bool sorted = SORTABLE && prm.shared_order != nullptr;
+    constexpr bool sorted = SORTED;        // own instantiation, see helmholtz_kernel
 #pragma unroll
     for (int a = 0; a < P; ++a) {
       uint32_t ea = enc[a];
@@ -522,7 +521,7 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
         }
       }
     }
-    if constexpr (SORTABLE) if (sorted) {   // shared slots in ascending node order
+    if constexpr (sorted) {   // shared slots in ascending node order
       uint32_t* codes = reinterpret_cast<uint32_t*>(s1);
       if (Tile::BLOCK > 64) __syncthreads();
       if (lane_ok) {
@@ -553,7 +552,7 @@ stokes_grad_t_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
 // exchange.  At P = 8 in 3D that removes 216 of the 512 nodes of every element
 // from both the scatter and the gather, and the field in between shrinks to
 // the element surfaces.  p_out receives D of the complete part.
-template <typename T, int P, int PP, int DIM, int GM>
+template <typename T, int P, int PP, int DIM, int GM, bool SORTED = false>
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 stokes_e_first_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
@@ -669,11 +668,11 @@ stokes_e_first_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
         if (DIM == 3) v += s1[o];
       }
       // (own position: staged for the sorted scatter of the shared slots)
-      if (TPE <= 64 && prm.shared_order && lane_ok) s0[o] = v;
+      if (SORTED && lane_ok) s0[o] = v;
       ua[a] = T(0);
       if (id != SFEM_IDX_PAD && !(ea & SFEM_IDX_DIRICHLET)) {
         if (ea & SFEM_IDX_SHARED) {
-          if (!(TPE <= 64 && prm.shared_order))
+          if (!SORTED)
             unsafeAtomicAdd(prm.out + (int64_t)id * ns + c * ks, v);
         } else {
           if (prm.scale)
@@ -683,7 +682,7 @@ stokes_e_first_kernel(StokesParams<T> prm, DMat<T, P> dm, IMat<T, P, PP> im) {
         }
       }
     }
-    if constexpr (TPE <= 64) if (prm.shared_order) {
+    if constexpr (SORTED) {
       uint32_t* codes = reinterpret_cast<uint32_t*>(s1);
       if (Tile::BLOCK > 64) __syncthreads();
       if (lane_ok) {
@@ -899,19 +898,28 @@ int launch_stokes(const StokesParams<T>& prm, int mode, hipStream_t stream) {
   for (int q = 0; q < P * PP; ++q)
     im.m[q] = prm.interp_host ? prm.interp_host[q] : T(0);
   const dim3 grid((unsigned)groups), block(Tile::BLOCK);
+  // sorted shared scatter: own instantiations, one-wave elements in 3D
+  constexpr bool CAN_SORT = DIM == 3 && Tile::TPE <= 64;
+  const bool sorted = CAN_SORT && prm.shared_order != nullptr;
 #define SFEM_LAUNCH_STOKES(GMV)                                               \
   if (mode == 2)                                                              \
     hipLaunchKernelGGL((stokes_convect_kernel<T, P, DIM, GMV>), grid, block,  \
                        0, stream, prm, dm);                                   \
+  else if (mode == 3 && sorted)                                               \
+    hipLaunchKernelGGL((stokes_e_first_kernel<T, P, PP, DIM, GMV, CAN_SORT>), \
+                       grid, block, 0, stream, prm, dm, im);                  \
   else if (mode == 3)                                                         \
-    hipLaunchKernelGGL((stokes_e_first_kernel<T, P, PP, DIM, GMV>), grid,     \
-                       block, 0, stream, prm, dm, im);                        \
+    hipLaunchKernelGGL((stokes_e_first_kernel<T, P, PP, DIM, GMV, false>),    \
+                       grid, block, 0, stream, prm, dm, im);                  \
   else if (mode == 4)                                                         \
     hipLaunchKernelGGL((stokes_div_kernel<T, P, PP, DIM, GMV, true>), grid,   \
                        block, 0, stream, prm, dm, im);                        \
+  else if (grad_t && sorted)                                                  \
+    hipLaunchKernelGGL((stokes_grad_t_kernel<T, P, PP, DIM, GMV, CAN_SORT>),  \
+                       grid, block, 0, stream, prm, dm, im);                  \
   else if (grad_t)                                                            \
-    hipLaunchKernelGGL((stokes_grad_t_kernel<T, P, PP, DIM, GMV>), grid,      \
-                       block, 0, stream, prm, dm, im);                        \
+    hipLaunchKernelGGL((stokes_grad_t_kernel<T, P, PP, DIM, GMV, false>),     \
+                       grid, block, 0, stream, prm, dm, im);                  \
   else                                                                        \
     hipLaunchKernelGGL((stokes_div_kernel<T, P, PP, DIM, GMV>), grid, block,  \
                        0, stream, prm, dm, im)
