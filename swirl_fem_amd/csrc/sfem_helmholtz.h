@@ -429,8 +429,11 @@ __device__ __forceinline__ void scatter_shared_sorted(
 
 // SORTED: the sorted shared scatter below, its own instantiation (compiled
 // together with the slot-order scatter it cost registers in both).
+// MASS: lambda0 != 0 (decided at launch).  The pure stiffness kernels carry no
+// mass-term code: 15-20 VGPRs less, which is what lets the multilinear kernel
+// take the sorted path without spilling.
 template <typename T, int P, int DIM, bool GS, bool SCALAR, int GM,
-          bool SORTED = false>
+          bool SORTED = false, bool MASS = true>
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
@@ -459,7 +462,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   // compiler has nothing to hoist out of it and spill)
   const int nc = SCALAR ? 1 : prm.ncomp;
   const int64_t ns = prm.node_stride, ks = prm.comp_stride;
-  const bool has_mass = prm.lambda0 != T(0);
+  constexpr bool has_mass = MASS;
   const bool has_stiff = prm.lambda1 != T(0);
 
   // Owner layout: this lane holds nodes (a, i, j), a = 0..P-1, i.e. element
@@ -711,19 +714,29 @@ int launch_helmholtz(const HelmholtzParams<T>& prm, hipStream_t stream) {
       make_dmat<T, P>(prm.dmat_host, prm.weights_host, prm.nodes_host);
   const dim3 grid((unsigned)groups), block(Tile::BLOCK);
   // One-wave elements in 3D can issue their atomics in node order.  Not the
-  // multilinear kernels: they sit at the 128-VGPR budget of 4 waves per SIMD
-  // and the sorted path spills (1.09 vs 1.04 ms; 1.13 ms with 3 waves).
+  // multilinear kernels WITH a mass term: they sit at the 128-VGPR budget of
+  // 4 waves per SIMD and the sorted path spills (1.09 vs 1.04 ms; 1.13 ms
+  // with 3 waves).
   constexpr bool CAN_SORT = GS && DIM == 3 && Tile::TPE <= 64;
   const bool sorted = CAN_SORT && prm.shared_order && !prm.colored;
+  const bool mass = prm.lambda0 != T(0);
+#define SFEM_LAUNCH_SM(SC, GMV, PRM, MASSV)                                   \
+  do {                                                                        \
+    constexpr bool SORT_GM =                                                  \
+        CAN_SORT && (GMV != GEO_MULTILINEAR || !(MASSV));                     \
+    if (sorted && SORT_GM)                                                    \
+      hipLaunchKernelGGL(                                                     \
+          (helmholtz_kernel<T, P, DIM, GS, SC, GMV, SORT_GM, MASSV>), grid,   \
+          block, 0, stream, PRM, dm);                                         \
+    else                                                                      \
+      hipLaunchKernelGGL(                                                     \
+          (helmholtz_kernel<T, P, DIM, GS, SC, GMV, false, MASSV>), grid,     \
+          block, 0, stream, PRM, dm);                                         \
+  } while (0)
 #define SFEM_LAUNCH_GM(SC, GMV, PRM)                                          \
   do {                                                                        \
-    constexpr bool SORT_GM = CAN_SORT && GMV != GEO_MULTILINEAR;              \
-    if (sorted && SORT_GM)                                                    \
-      hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, SC, GMV, SORT_GM>), \
-                         grid, block, 0, stream, PRM, dm);                    \
-    else                                                                      \
-      hipLaunchKernelGGL((helmholtz_kernel<T, P, DIM, GS, SC, GMV, false>),   \
-                         grid, block, 0, stream, PRM, dm);                    \
+    if (mass) SFEM_LAUNCH_SM(SC, GMV, PRM, true);                             \
+    else SFEM_LAUNCH_SM(SC, GMV, PRM, false);                                 \
   } while (0)
   if (prm.ncomp == 1) {
     switch (prm.geo_mode) {
@@ -739,6 +752,7 @@ int launch_helmholtz(const HelmholtzParams<T>& prm, hipStream_t stream) {
     SFEM_LAUNCH_GM(false, GEO_MULTILINEAR, prm);
   }
 #undef SFEM_LAUNCH_GM
+#undef SFEM_LAUNCH_SM
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }
