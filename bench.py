@@ -351,7 +351,7 @@ def main():
                               'of this command (profiles/traffic_r01.json, '
                               'profiles/r01_pmc_notes.md); null if this '
                               'workload was not profiled',
-            'kernel': 'sfem::helmholtz_kernel<%s, %d, 3, true, true, GM>' % (
+            'kernel': 'sfem::helmholtz_kernel<%s, %d, 3, true, true, GM, SORTED, MASS>' % (
                 'double' if args.dtype == 'f64' else 'float', P),
             'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg_bytes,
             'measured_stream_peak': stream_gbs,

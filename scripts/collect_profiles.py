@@ -30,7 +30,8 @@ shutil.copy(os.path.join(src, f'bench_{tag}_stored.json'), os.path.join(out, f'{
 
 def counter(mode, which):
   # GM template argument: 1 = affine (default mesh), 0 = stored factors
-  suffix = 'true, true, 1>' if mode == 'affine' else 'true, true, 0>'
+  # helmholtz_kernel<T, P, DIM, GS, SCALAR, GM, SORTED, MASS>
+  suffix = 'true, true, 1,' if mode == 'affine' else 'true, true, 0,'
   f = one(f'pmc_{tag}_{mode}_{which}/**/*_counter_collection.csv')
   vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
           if 'helmholtz_kernel' in r['Kernel_Name'] and suffix in r['Kernel_Name']]
