@@ -316,6 +316,41 @@ struct ElemGeom {
         b + (2 * lane_off + (uint32_t)(2 * a * TPE * sizeof(T))));
   }
 
+  // Multilinear 3D: (w / det) C C^T g with C = rows of cofactors, applied as
+  // C (C^T g) without forming the six G entries (21 instead of 39 operations
+  // per point).  Returns the three components and, optionally, W = w det.
+  __device__ __forceinline__ void apply_multilinear3(
+      const DMat<T, P>& dm, int a, bool want_w, T g0, T g1, T g2, T& o0, T& o1,
+      T& o2, T& Wm) const {
+    const T r = dm.x[a];
+    const T wq = wbc * dm.w[a];
+    T R1[3], R2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      R1[c] = p1[c] + r * q1[c];
+      R2[c] = p2[c] + r * q2[c];
+    }
+    const T c0[3] = {R1[1] * R2[2] - R1[2] * R2[1],
+                     R1[2] * R2[0] - R1[0] * R2[2],
+                     R1[0] * R2[1] - R1[1] * R2[0]};
+    const T c1[3] = {R2[1] * r0[2] - R2[2] * r0[1],
+                     R2[2] * r0[0] - R2[0] * r0[2],
+                     R2[0] * r0[1] - R2[1] * r0[0]};
+    const T c2[3] = {r0[1] * R1[2] - r0[2] * R1[1],
+                     r0[2] * R1[0] - r0[0] * R1[2],
+                     r0[0] * R1[1] - r0[1] * R1[0]};
+    const T det = r0[0] * c0[0] + r0[1] * c0[1] + r0[2] * c0[2];
+    Wm = want_w ? wq * det : T(0);
+    const T sc = wq / det;
+    T y[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      y[k] = sc * (c0[k] * g0 + c1[k] * g1 + c2[k] * g2);
+    o0 = c0[0] * y[0] + c0[1] * y[1] + c0[2] * y[2];
+    o1 = c1[0] * y[0] + c1[1] * y[1] + c1[2] * y[2];
+    o2 = c2[0] * y[0] + c2[1] * y[1] + c2[2] * y[2];
+  }
+
   // Factors at the lane's node of slice a: G[0..NG) upper triangle, W.
   // want_g / want_w are compile-time after inlining in the callers.
   __device__ __forceinline__ void factors(const DMat<T, P>& dm, int a,
@@ -555,6 +590,14 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
           const int o = a * SA + i * SB + j;
           T G[6], Wm;
           constexpr bool FUSE_W = GM != GEO_POINT;
+          if (GM == GEO_MULTILINEAR && DIM == 3) {
+            T o0, o1, o2;
+            geom.apply_multilinear3(dm, a, has_mass, d0[a], s0[o], s1[o], o0,
+                                    o1, o2, Wm);
+            if (has_mass) acc[a] = prm.lambda0 * Wm * ua[a];
+            w0[a] = o0; s0[o] = o1; s1[o] = o2;
+            continue;
+          }
           geom.factors(dm, a, true, FUSE_W && has_mass, G, Wm);
           if (FUSE_W && has_mass) acc[a] = prm.lambda0 * Wm * ua[a];
           if (DIM == 3) {
