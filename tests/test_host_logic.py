@@ -500,3 +500,32 @@ def test_kernels_refuse_cpu_tensors():
     cg(lambda x: x, torch.ones(3, dtype=torch.float64))
   with pytest.raises(TypeError):
     _ops._dtype_code(torch.zeros(1, dtype=torch.int32))
+
+
+def test_shared_slot_order_lists_shared_slots_by_node():
+  """`operators.shared_slot_order`: per element the SHARED, non-Dirichlet,
+  non-padding slots in ascending node order, 0xFFFF padded (the order in which
+  the assembled kernels issue their atomics)."""
+  import torch
+  from swirl_fem_amd.core.operators import shared_slot_order
+  rng = np.random.default_rng(0)
+  E, n, N = 7, 27, 200
+  ids = np.stack([rng.permutation(N)[:n] for _ in range(E)]).astype(np.int64)
+  shared = rng.random((E, n)) < 0.6
+  dirichlet = rng.random((E, n)) < 0.15
+  pad = rng.random((E, n)) < 0.05
+  ids[pad] = 0x3FFFFFFF
+  shared[0] = False                       # an element without shared slots
+  code = ids | (shared.astype(np.int64) << 30) | (dirichlet.astype(np.int64) << 31)
+  enc = torch.from_numpy(code.astype(np.uint32).view(np.int32))
+  tab = shared_slot_order(enc)
+  take = shared & ~dirichlet & ~pad
+  assert tab.dtype == torch.int16 and tab.shape == (E, take.sum(1).max())
+  got = tab.numpy().view(np.uint16)
+  for e in range(E):
+    want = np.nonzero(take[e])[0]
+    want = want[np.argsort(ids[e, want], kind='stable')]
+    np.testing.assert_array_equal(got[e, :len(want)], want)
+    assert (got[e, len(want):] == 0xFFFF).all()
+  none = torch.from_numpy((ids & 0x3FFFFFFF).astype(np.int32))
+  assert shared_slot_order(none) is None
