@@ -71,10 +71,15 @@ __host__ __device__ constexpr int round_up(int a, int b) {
   return (a + b - 1) / b * b;
 }
 
-template <typename T, int P, int DIM>
+// PAD: rows of the LDS tensor padded to an odd length (no bank conflicts in the
+// transposes).  Unpadded rows save 1/9 of the LDS at P = 8: 20 instead of 17
+// one-wave workgroups per CU, which pays where the registers allow 5 waves per
+// SIMD (the affine kernels: 0.765 -> 0.730 ms) and costs 1 % where they do
+// not (stored factors), hence a per-kernel choice.
+template <typename T, int P, int DIM, bool PAD = true>
 struct HelmholtzTile {
   static constexpr int TPE = DIM == 3 ? P * P : P;       // lanes per element
-  static constexpr int SB = P | 1;                       // padded row stride
+  static constexpr int SB = PAD ? (P | 1) : P;           // row stride
   static constexpr int SA = DIM == 3 ? P * SB : SB;      // axis-0 stride
   static constexpr int ELEM_WORDS = P * SA;              // one padded tensor
   static constexpr int LDS_PER_ELEM = 2 * ELEM_WORDS * (int)sizeof(T);
@@ -444,11 +449,11 @@ struct ElemGeom {
 // Second half of the sorted shared scatter (see helmholtz_kernel): the lanes of
 // one element walk its SHARED slots in ascending node order; `vals` is the
 // padded element tensor in LDS, `codes` the element's `enc` row in slot order.
-template <typename T, int P, int DIM>
+template <typename T, int P, int DIM, bool PAD = true>
 __device__ __forceinline__ void scatter_shared_sorted(
     const uint16_t* so, int stride, int t, const T* vals,
     const uint32_t* codes, T* dst, int64_t ns) {
-  using Tile = HelmholtzTile<T, P, DIM>;
+  using Tile = HelmholtzTile<T, P, DIM, PAD>;
   constexpr int TPE = Tile::TPE, SA = Tile::SA, SB = Tile::SB;
   for (int q = t; q < stride; q += TPE) {
     const uint32_t slot = so[q];
@@ -472,7 +477,10 @@ template <typename T, int P, int DIM, bool GS, bool SCALAR, int GM,
 __global__ void __launch_bounds__((HelmholtzTile<T, P, DIM>::BLOCK),
                                   (HelmholtzTile<T, P, DIM>::MINW))
 helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
-  using Tile = HelmholtzTile<T, P, DIM>;
+  // unpadded LDS rows for the light (affine) kernels at P = 8, see the tile
+  constexpr bool PAD =
+      !(GS && SCALAR && DIM == 3 && P == 8 && GM == GEO_AFFINE);
+  using Tile = HelmholtzTile<T, P, DIM, PAD>;
   constexpr int TPE = Tile::TPE, SA = Tile::SA, SB = Tile::SB;
   constexpr int EPB = Tile::EPB, W = Tile::ELEM_WORDS;
   constexpr int N = DIM == 3 ? P * P * P : P * P;        // nodes per element
@@ -590,7 +598,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
           const int o = a * SA + i * SB + j;
           T G[6], Wm;
           constexpr bool FUSE_W = GM != GEO_POINT;
-          if (GM == GEO_MULTILINEAR && DIM == 3) {
+          if constexpr (GM == GEO_MULTILINEAR && DIM == 3) {
             T o0, o1, o2;
             geom.apply_multilinear3(dm, a, has_mass, d0[a], s0[o], s1[o], o0,
                                     o1, o2, Wm);
@@ -700,7 +708,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
       }
       __syncthreads();
       if (active)
-        scatter_shared_sorted<T, P, DIM>(
+        scatter_shared_sorted<T, P, DIM, PAD>(
             prm.shared_order + e * prm.shared_stride, prm.shared_stride, t, s0,
             codes, og + k * ks, ns);
     }
