@@ -61,6 +61,41 @@ int main(void) {
     CHECK(sfem_dot(du, du, 4, dres, SFEM_F64, NULL) == SFEM_OK, "dot");
     HIP(hipMemcpy(&res, dres, sizeof res, hipMemcpyDeviceToHost));
     CHECK(res == 30.0, "dot = %g", res);
+    /* periodic QQ^T from the classes themselves: {0, 3} and {1, 2} */
+    {
+      const double v[4] = {1.0, 2.0, 3.0, 4.0};
+      const int32_t members[4] = {0, 3, 1, 2}, offsets[3] = {0, 2, 4};
+      double* dv = (double*)to_device(v, sizeof v);
+      int32_t* dm = (int32_t*)to_device(members, sizeof members);
+      int32_t* dof = (int32_t*)to_device(offsets, sizeof offsets);
+      CHECK(sfem_exchange_classes(dv, dm, dof, 2, 1, 1, 1, SFEM_F64, NULL) ==
+                SFEM_OK, "%s", sfem_last_error());
+      double q[4];
+      HIP(hipMemcpy(q, dv, sizeof q, hipMemcpyDeviceToHost));
+      CHECK(q[0] == 5.0 && q[3] == 5.0 && q[1] == 5.0 && q[2] == 5.0,
+            "exchange_classes");
+      /* out = w - (b . w / total) 1, with w . out on the side */
+      const double b[4] = {1.0, 1.0, 1.0, 1.0};
+      double* dbb = (double*)to_device(b, sizeof b);
+      double* dpart = (double*)to_device(NULL, SFEM_DOT_SLOTS * sizeof(double));
+      double* dwz = (double*)to_device(NULL, sizeof(double));
+      HIP(hipMemset(dwz, 0, sizeof(double)));
+      HIP(hipMemcpy(dv, v, sizeof v, hipMemcpyHostToDevice));
+      CHECK(sfem_subtract_weighted_mean(dv, dbb, 4.0, dv, dpart, 4, dwz,
+                                        SFEM_F64, NULL) == SFEM_OK,
+            "%s", sfem_last_error());
+      double wz = 0.0;
+      HIP(hipMemcpy(q, dv, sizeof q, hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(&wz, dwz, sizeof wz, hipMemcpyDeviceToHost));
+      CHECK(q[0] == -1.5 && q[1] == -0.5 && q[2] == 0.5 && q[3] == 1.5,
+            "subtract_weighted_mean");
+      CHECK(wz == 5.0, "w . out = %g", wz);   /* sum v_i (v_i - 2.5) */
+      CHECK(sfem_zero_strips(dv + 1, 1, 2, 2, SFEM_F64, NULL) == SFEM_OK,
+            "%s", sfem_last_error());
+      HIP(hipMemcpy(q, dv, sizeof q, hipMemcpyDeviceToHost));
+      CHECK(q[0] == -1.5 && q[1] == 0.0 && q[2] == 0.5 && q[3] == 0.0,
+            "zero_strips");
+    }
     /* invalid arguments come back as a status + message, never a crash */
     CHECK(sfem_gather(du, di, dl, -1, 0.0, SFEM_F64, NULL) != SFEM_OK, "bad count");
     CHECK(strlen(sfem_last_error()) > 0, "error message");
