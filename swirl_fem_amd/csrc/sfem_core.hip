@@ -826,7 +826,8 @@ int sfem_zero_strips(void* base, int64_t strip_len, int64_t strip_stride,
   const size_t esz = dtype == SFEM_F64 ? 8 : 4;
   // large ranges: the runtime's fill runs at stream bandwidth; short ones are
   // bound by the number of launches, so all strips go into one
-  if ((size_t)strip_len * esz >= ((size_t)8 << 20)) {
+  // (measured, 3 strips: 34 MB 16.4 vs 20.6 us, 64 MB 27 vs 31, 128 MB 73 vs 65)
+  if ((size_t)strip_len * esz > ((size_t)64 << 20)) {
     for (int s = 0; s < nstrips; ++s)
       SFEM_HIP(hipMemsetAsync((char*)base + (size_t)s * strip_stride * esz, 0,
                               (size_t)strip_len * esz, as_stream(stream)));
