@@ -38,18 +38,36 @@ def algorithmic_bytes_per_apply(E, n, N, sizeof=8, ngeo=6):
   return 4 * E * n + sizeof * N + ngeo * sizeof * E * n + sizeof * N
 
 
+def kernel_bytes_per_apply(E, n, N, sizeof, ngeo, num_onthefly, num_stored):
+  """Bytes the timed launch HAS to move: idx 4 E n + u s N + out s N + the
+  geometry it actually reads -- 24 reals per affine / multilinear element
+  (their factors are evaluated in registers), `ngeo` reals per point only for
+  elements with stored factors."""
+  return (4 * E * n + 2 * sizeof * N + 24 * sizeof * num_onthefly +
+          ngeo * sizeof * n * num_stored)
+
+
+TRAFFIC_FILE = 'profiles/traffic_r02.json'
+
+
 def measured_traffic(n, p, dtype, geometry, jitter):
-  """HBM bytes per launch of the dominant kernel measured with rocprofv3 PMC
-  counters for this exact workload (profiles/traffic_r01.json), or None."""
+  """(HBM bytes per launch of the dominant kernel, git sha of the build they
+  were measured on) from the rocprofv3 PMC passes of this exact command
+  (`scripts/pmc_traffic.sh` writes TRAFFIC_FILE), or (None, None).  PMC
+  counters cannot be read from inside the process, so the figure is a
+  profile of an earlier run of the same command, stamped with its commit."""
   key = 'n%d_p%d_%s_%s' % (n, p, dtype, 'stored' if geometry == 'stored'
                            else 'auto')
-  path = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
+  if jitter:
+    key += '_jitter'
   try:
-    with open(path) as f:
+    with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
       entry = json.load(f).get(key)
   except (OSError, ValueError):
-    return None
-  return None if entry is None else entry['bytes']
+    return None, None
+  if entry is None:
+    return None, None
+  return entry['bytes'], entry.get('git_sha')
 
 
 def block_grid(world):
@@ -96,6 +114,77 @@ def cpu_baseline(P, budget_s=12.0):
   }
 
 
+def _free_port():
+  import socket
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    return sock.getsockname()[1]
+
+
+def launch_ranks(n):
+  """Runs this script as `n` ranks (one process per GPU) and returns the exit
+  code: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` with a
+  local rendezvous, the command line passed through.  The parent has not
+  initialised the GPU (it has not even imported torch)."""
+  import subprocess
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+         '--master-port', str(_free_port()), os.path.abspath(__file__)
+         ] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n)))
+  return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+  """Everything of the N-rank bench path that needs no GPU: rendezvous (gloo),
+  this rank's block and neighbour plan, one QQ^T exchange of the interface
+  values and the scalar all-reduce, on CPU tensors."""
+  import torch
+  import torch.distributed as dist
+  from swirl_fem_amd.distributed import blocks, comm
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+  grid_b = block_grid(world)
+  periodic_dims = (0, 1, 2) if args.periodic and world > 1 else ()
+  part = blocks.build_block_partition(args.n, args.p + 1, grid_b, rank,
+                                      device='cpu',
+                                      periodic_dims=periodic_dims)
+  ones = torch.ones(part.mesh.num_nodes, dtype=torch.float64)
+  holders = ones.clone()
+  sent = 0
+  if world > 1:
+    idx = [torch.as_tensor(ix, dtype=torch.int64) for ix in part.plan.indices]
+    recv = comm.exchange_buffers(part.plan, [ones[ix] for ix in idx])
+    for rb, ix in zip(recv, idx):
+      holders.index_add_(0, ix, rb)
+      sent += ix.numel()
+  # every DOF counted once: sum over ranks of sum_i 1 / holders_i = N_global
+  total = torch.tensor([float((1.0 / holders).sum())], dtype=torch.float64)
+  if world > 1:
+    comm.all_reduce_sum_(total)
+  ok = abs(float(total) - part.num_global_nodes) < 1e-6 * part.num_global_nodes
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'GDOF/s per CG iteration, 3D p=%d Laplacian' % args.p,
+        'value': None, 'unit': 'GDOF/s', 'n_gpus': world, 'dry_run': True,
+        'config': {'workload': 'launch rehearsal on CPU: %d^3 elements per '
+                               'rank, p=%d' % (args.n, args.p),
+                   'blocks': 'x'.join(map(str, grid_b)),
+                   'backend': 'gloo', 'world_size_seen':
+                       dist.get_world_size() if world > 1 else 1,
+                   'dofs_global': part.num_global_nodes,
+                   'interface_values_sent_rank0': sent,
+                   'dof_count_via_exchange_ok': bool(ok)}}))
+  if world > 1:
+    dist.destroy_process_group()
+  if not ok:
+    raise SystemExit('dry run: the exchanged holder counts do not add up')
+  return 0
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -138,7 +227,27 @@ def main():
                        'interior elements')
   ap.add_argument('--jitter', type=float, default=0.0,
                   help='smooth mesh deformation amplitude (fraction of h)')
+  ap.add_argument('--dry-run', action='store_true',
+                  help='rehearse launch, rendezvous, block build and one '
+                       'interface exchange on CPU tensors (gloo) and print a '
+                       'line with value null; nothing is timed and no kernel '
+                       'runs (the kernels have no CPU path)')
   args = ap.parse_args()
+
+  world_env = os.environ.get('WORLD_SIZE')
+  if world_env is None and args.gpus > 1:
+    # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh
+    # child processes, BEFORE this process touches the GPU (it never does)
+    raise SystemExit(launch_ranks(args.gpus))
+  world = int(world_env or '1')
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    raise SystemExit(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; '
+                     'the block grid and the reported rate follow the ranks '
+                     'that actually run')
+  if args.dry_run:
+    return dry_run(args, world, rank)
 
   import torch
   import torch.distributed as dist
@@ -146,12 +255,9 @@ def main():
   from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
   from swirl_fem_amd.linalg.cg import CGRunner
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch N>1 with torch.distributed.run (see docstring)')
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py: no GPU visible; the kernels have no CPU path '
+                     '(use --dry-run to rehearse the launch on CPU)')
   if args.backend == 'gloo':
     local_rank %= torch.cuda.device_count()
   torch.cuda.set_device(local_rank)
@@ -245,24 +351,28 @@ def main():
   ms_per_step = 1e3 * elapsed / args.steps
   value = N_global / (elapsed / args.steps) / 1e9
 
-  # ---- roofline of the dominant kernel: HIP events around the kernel only
+  # ---- roofline of the dominant kernel: HIP events around ONE apply as the
+  # solver issues it -- the fused kernel and whatever it needs around it (the
+  # clearing of the atomically accumulated node range, when there is one)
   u = run.p
-  lo, hi = op.zero_range
-  ev = [(torch.cuda.Event(enable_timing=True),
-         torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
   from swirl_fem_amd import _ops
-  for _ in range(3):
-    op.apply(u, args.mass_coeff, 1.0, out=out_buf)
-  torch.cuda.synchronize()
-  for s0, s1 in ev:
-    if hi > lo:
-      out_buf[lo:hi].zero_()                 # outside the event pair
-    s0.record()
-    op.apply(u, args.mass_coeff, 1.0, out=out_buf, zero=False)
-    s1.record()
-  torch.cuda.synchronize()
-  kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
-  # apply incl. the zero-fill of the shared range, as the solver issues it
+
+  def time_apply(operator):
+    for _ in range(3):
+      operator.apply(u, args.mass_coeff, 1.0, out=out_buf)
+    torch.cuda.synchronize()
+    pairs = [(torch.cuda.Event(enable_timing=True),
+              torch.cuda.Event(enable_timing=True))
+             for _ in range(args.steps)]
+    for e0, e1 in pairs:
+      e0.record()
+      operator.apply(u, args.mass_coeff, 1.0, out=out_buf)
+      e1.record()
+    torch.cuda.synchronize()
+    return float(np.mean([x.elapsed_time(y) for x, y in pairs]))
+
+  kern_ms = time_apply(op)
+  # back-to-back applies (no event between them)
   s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
       enable_timing=True)
   s0.record()
@@ -271,25 +381,35 @@ def main():
   s1.record()
   torch.cuda.synchronize()
   apply_ms = s0.elapsed_time(s1) / args.steps
+  per_rank = None
+  if world > 1:
+    # per-rank figures: local apply (above) and the interface exchange alone
+    from swirl_fem_amd.distributed import comm
+    w = torch.zeros_like(b)
+    for _ in range(3):
+      comm.neighbor_exchange_(w, part.plan)
+    barrier()
+    s0.record()
+    for _ in range(args.steps):
+      comm.neighbor_exchange_(w, part.plan)
+    s1.record()
+    torch.cuda.synchronize()
+    exchange_ms = s0.elapsed_time(s1) / args.steps
+    mine = torch.tensor([apply_ms, exchange_ms, float(part.plan.num_shared)],
+                        dtype=torch.float64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per_rank = {'apply_ms': [float(t[0]) for t in every],
+                'exchange_ms': [float(t[1]) for t in every],
+                'interface_values': [int(t[2]) for t in every]}
+    del w
   # the same mesh through the general-geometry path (6 stored factors per
   # point are READ): the kernel whose traffic the stored-factor model describes
   general = None
   if world == 1 and args.geometry == 'auto' and not args.no_general:
     op_g = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
                                   geometry='stored')
-    for _ in range(3):
-      op_g.apply(u, args.mass_coeff, 1.0, out=out_buf)
-    torch.cuda.synchronize()
-    evg = [(torch.cuda.Event(enable_timing=True),
-            torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for s0, s1 in evg:
-      if hi > lo:
-        out_buf[lo:hi].zero_()
-      s0.record()
-      op_g.apply(u, args.mass_coeff, 1.0, out=out_buf, zero=False)
-      s1.record()
-    torch.cuda.synchronize()
-    general = float(np.mean([a.elapsed_time(b_) for a, b_ in evg]))
+    general = time_apply(op_g)
     del op_g
   # device stream figure beside the vendor peak: y = a x + b y over
   # N-vectors, 3 passes
@@ -305,9 +425,16 @@ def main():
   torch.cuda.synchronize()
   stream_gbs = 3 * xs.numel() * sizeof / (s0.elapsed_time(s1) / 20 * 1e-3) / 1e9
   del xs, ys
-  alg_bytes = algorithmic_bytes_per_apply(
-      E, n, N_local, sizeof=sizeof, ngeo=7 if args.mass_coeff else 6)
-  achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+  ngeo = 7 if args.mass_coeff else 6
+  model_bytes = algorithmic_bytes_per_apply(E, n, N_local, sizeof=sizeof,
+                                            ngeo=ngeo)
+  kernel_bytes = kernel_bytes_per_apply(
+      E, n, N_local, sizeof, ngeo, op.num_affine + op.num_multilinear,
+      op.num_curved)
+  achieved = kernel_bytes / (kern_ms * 1e-3) / 1e9
+  traffic, traffic_sha = measured_traffic(args.n, args.p, args.dtype,
+                                          args.geometry, args.jitter)
+  passes = run.vector_passes if hasattr(run, 'vector_passes') else 8
 
   if rank == 0:
     res = {
@@ -334,6 +461,8 @@ def main():
             if world > 1 else None,
             'backend': ('rccl' if args.backend == 'nccl' else 'gloo '
                         '(rehearsal)') if world > 1 else None,
+            'world_size_seen': dist.get_world_size() if world > 1 else 1,
+            'per_rank': per_rank,
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
             'apply_ms': apply_ms, 'setup_s': setup_s,
             'geometry': ('%s: %d affine + %d multilinear elements (factors '
@@ -345,40 +474,56 @@ def main():
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': measured_traffic(args.n, args.p, args.dtype,
-                                        args.geometry, args.jitter),
+            'traffic': traffic,
+            'traffic_profiled_at': traffic_sha,
             'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
-                              'of this command (profiles/traffic_r01.json, '
-                              'profiles/r01_pmc_notes.md); null if this '
-                              'workload was not profiled',
-            'kernel': 'sfem::helmholtz_kernel<%s, %d, 3, true, true, GM, SORTED, MASS>' % (
-                'double' if args.dtype == 'f64' else 'float', P),
-            'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': alg_bytes,
+                              'of this command on the commit named in '
+                              'traffic_profiled_at (%s; FETCH_SIZE doubled as '
+                              'MI355X_MICROARCH.md prescribes); null if this '
+                              'workload was not profiled' % TRAFFIC_FILE,
+            'kernel': op.kernel_name(args.mass_coeff, 1.0),
+            'kernel_ms': kern_ms,
+            'kernel_ms_covers': 'one apply as the solver issues it: the fused '
+                                'kernel plus the clearing of the atomically '
+                                'accumulated node range it needs, if any',
+            'bytes_per_launch': kernel_bytes,
+            'bytes_model': 'idx 4 E n + u s N + out s N + 24 reals per affine '
+                           '/ multilinear element + %d reals per point of '
+                           'elements with stored factors' % ngeo,
             'measured_stream_peak': stream_gbs,
             'frac_of_measured_stream': achieved / stream_gbs,
-            'note': ('algorithmic bytes are the stored-6-factor model of '
-                     'SURVEY 8(d) for every element; affine / multilinear '
-                     'elements move fewer bytes than the model (factors are '
-                     'recomputed in registers, not read)'),
+            # NOT an HBM fraction: the SURVEY 8(d) stored-6-factor model
+            # charges 6 factors per point to every element; on affine /
+            # multilinear elements this kernel never reads them, so the ratio
+            # may exceed 1.  It compares GDOF/s with the model's 85.9 GDOF/s.
+            'model_gdofs_ratio': model_bytes / (kern_ms * 1e-3) / 1e9 /
+                                 HBM_PEAK_GBS,
+            'model_bytes_per_launch': model_bytes,
         },
     }
-    cg_bytes = alg_bytes + 11 * sizeof * N_local     # SURVEY 8(d) model
+    cg_bytes = kernel_bytes + passes * sizeof * N_local
     res['roofline_cg_iteration'] = {
         'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
         'achieved': cg_bytes / (ms_per_step * 1e-3) / 1e9,
         'frac': cg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        'algorithmic_bytes_per_iteration': cg_bytes,
-        'note': 'whole iteration against SURVEY 8(d): stored-factor apply + 11 '
-                'N-vector passes; this build issues 8 passes (p.Ap and r.r '
-                'fused, x and p updated together)'}
+        'bytes_per_iteration': cg_bytes,
+        'vector_passes': passes,
+        'model_gdofs_ratio': (model_bytes + 11 * sizeof * N_local) /
+                             (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        'note': 'bytes this build moves per iteration: the apply above + %d '
+                'N-vector passes (p.Ap and r.r fused into kernels that stream '
+                'the vectors anyway); model_gdofs_ratio is against SURVEY '
+                "8(d)'s stored-factor apply + 11 passes" % passes}
     if general is not None:
+      stored_bytes = kernel_bytes_per_apply(E, n, N_local, sizeof, ngeo, 0, E)
       res['roofline_stored_factors'] = {
-          'bound': 'hbm', 'achieved': alg_bytes / (general * 1e-3) / 1e9,
+          'bound': 'hbm', 'achieved': stored_bytes / (general * 1e-3) / 1e9,
           'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-          'frac': alg_bytes / (general * 1e-3) / 1e9 / HBM_PEAK_GBS,
-          'kernel_ms': general,
+          'frac': stored_bytes / (general * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          'kernel_ms': general, 'bytes_per_launch': stored_bytes,
           'kernel': 'same launch with geometry=stored (GM=0): every element '
-                    'reads its 6 factors per point, as curved elements do'}
+                    'reads its %d factors per point, as curved elements do '
+                    '(= the SURVEY 8(d) byte model)' % ngeo}
     if world == 1 and not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(P)
     else:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFEM_ABI_VERSION 2
+#define SFEM_ABI_VERSION 3
 
 enum { SFEM_F32 = 0, SFEM_F64 = 1 };
 enum {
@@ -363,6 +363,12 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *   [0] gamma = r.M r   [1] p.Ap   [2] gamma_new   [3] alpha   [4] beta
  *   [5] b.b   [6] atol2 = max(tol^2 b.b, atol^2)   [7] done (0/1)
  *   [8] iterations   [9] an iteration is open (phases 5 / 6)
+ *   [10] status, SFEM_CG_STATUS_*: why `done` was raised.  Beyond the
+ *        reference's stop rule (cg.py:68-73, which reads a negative or NaN
+ *        r.Mr as "converged" and divides by any p.Ap) the solve stops with
+ *        BAD_GAMMA when r.Mr is negative or not finite and with BAD_PAP when
+ *        p.Ap is not positive and finite (checked before that iteration's
+ *        updates, so x is the last good iterate).
  * Once `done` is set every kernel below is a no-op, so the host may run ahead
  * and poll [7] asynchronously; the iterate and the iteration count are exactly
  * those of a loop that tests the condition of cg.py:68-73 every iteration.
@@ -390,6 +396,11 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *                      r -= alpha Ap (+ gamma_new += r.r), then, once beta is
  *                      known,  x += alpha p;  p = z + beta p                   */
 #define SFEM_CG_NSCALARS 16
+#define SFEM_CG_STATUS_RUNNING 0.0
+#define SFEM_CG_STATUS_CONVERGED 1.0
+#define SFEM_CG_STATUS_MAXITER 2.0
+#define SFEM_CG_STATUS_BAD_PAP 3.0
+#define SFEM_CG_STATUS_BAD_GAMMA 4.0
 int sfem_dot(const void* a, const void* b, int64_t count, double* result,
              int dtype, sfem_stream_t stream);
 int sfem_dot_accumulate(const void* a, const void* b, int64_t count,

@@ -12,10 +12,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsfem_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SFEM_F32, SFEM_F64 = 0, 1
 SFEM_CG_NSCALARS = 16
+CG_STATUS = {0: 'running', 1: 'converged', 2: 'maxiter', 3: 'breakdown_pAp',
+             4: 'breakdown_gamma'}
 SFEM_DOT_SLOTS = 1024
 
 c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,

@@ -421,6 +421,17 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       shared_stride=0 if so is None or enc is None else so.shape[1])
 
 
+def helmholtz_kernel_name(real, P, ndim, scalar, geo_mode, part, mass):
+  """Mirror of `launch_helmholtz`'s choice (csrc/sfem_helmholtz.h)."""
+  tpe = P * P if ndim == 3 else P
+  can_sort = ndim == 3 and tpe <= 64
+  sort = (can_sort and part.get('shared_order') is not None and
+          not part.get('colored') and not (geo_mode == 3 and mass))
+  b = lambda v: 'true' if v else 'false'
+  return 'sfem::helmholtz_kernel<%s, %d, %d, true, %s, %d, %s, %s>' % (
+      real, P, ndim, b(scalar), geo_mode, b(sort), b(mass))
+
+
 def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
                     zero_range, dot_out=None):
   """out <- mask * scatter((l0 B + l1 A)_local(gather(u))).

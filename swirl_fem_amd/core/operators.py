@@ -262,6 +262,19 @@ class HelmholtzOperator:
     it also offers `apply_with_dot(u, partials)` (fused p.Ap)."""
     return FusedLinearOperator(self, lambda0, lambda1)
 
+  def kernel_name(self, lambda0=0.0, lambda1=1.0, ncomp=1):
+    """Name(s) of the kernel instantiation(s) `apply` launches, as they appear
+    in a rocprofv3 kernel trace (one per geometry kind present)."""
+    mesh = self.fespace.mesh
+    real = 'double' if self.fespace.dtype == torch.float64 else 'float'
+    P = mesh.gridpoints_1d.num_points
+    names = []
+    for part in self.parts:
+      gm = part['geo_mode']
+      names.append(_ops.helmholtz_kernel_name(
+          real, P, mesh.ndim, ncomp == 1, gm, part, lambda0 != 0))
+    return ' + '.join(sorted(set(names)))
+
 
 class FusedLinearOperator:
   """Callable operator with a fused `u . A(u)` for `linalg.cg.cg`."""

@@ -579,6 +579,48 @@ static void launch_update_r(bool fuse_rr, bool nt, int grid, hipStream_t stream,
 // phase 1 (gamma_new accumulated in [2]): beta = gamma_new / gamma;
 //     gamma <- gamma_new; clear pAp; ++iterations;
 //     done <- !(gamma > atol2) or iterations >= maxiter   (cg.py:68-73)
+// Breakdown guards (scalars[10], SFEM_CG_STATUS_*): the reference's stop rule
+// `!(gamma > atol2)` (cg.py:68-73) reads a negative or NaN r.Mr as converged
+// and divides by any p.Ap.  Both happen for real in the reference-convention
+// partitioned solve, whose r.QQ^T r is a sum over ranks of terms that only
+// cancel across ranks (-1e-19 |b|^2 is typical at tight tolerances): the solve
+// then stops and says why instead of returning a wrong answer as converged.
+__device__ __forceinline__ bool cg_bad_gamma(double g) {
+  return !(g >= 0.0) || !(g <= 1.7976931348623157e308);
+}
+__device__ __forceinline__ bool cg_bad_pap(double v) {
+  return !(v > 0.0) || !(v <= 1.7976931348623157e308);
+}
+// closes an iteration: beta, gamma <- gamma_new, counter, stop test
+__device__ __forceinline__ void cg_close_iteration(double* scalars,
+                                                   double maxiter) {
+  const double g = scalars[2];
+  scalars[4] = g / scalars[0];
+  scalars[0] = g;
+  scalars[8] += 1.0;
+  if (cg_bad_gamma(g)) {
+    scalars[10] = SFEM_CG_STATUS_BAD_GAMMA;
+    scalars[7] = 1.0;
+  } else if (!(g > scalars[6])) {
+    scalars[10] = SFEM_CG_STATUS_CONVERGED;
+    scalars[7] = 1.0;
+  } else if (scalars[8] >= maxiter) {
+    scalars[10] = SFEM_CG_STATUS_MAXITER;
+    scalars[7] = 1.0;
+  }
+}
+// alpha = gamma / p.Ap, or stop (before this iteration's updates) when the
+// operator is not positive along p
+__device__ __forceinline__ void cg_set_alpha(double* scalars, double pap) {
+  if (cg_bad_pap(pap)) {
+    scalars[10] = SFEM_CG_STATUS_BAD_PAP;
+    scalars[7] = 1.0;
+    return;
+  }
+  scalars[3] = scalars[0] / pap;
+  scalars[2] = 0.0;
+}
+
 __global__ void __launch_bounds__(256)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
                  double atol, double* partials) {
@@ -600,20 +642,14 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     }
     if (tid != 0 || scalars[7] != 0.0) return;
     if (scalars[9] != 0.0) {
-      scalars[4] = scalars[2] / scalars[0];
-      scalars[0] = scalars[2];
-      scalars[8] += 1.0;
       scalars[9] = 0.0;
-      if (!(scalars[0] > scalars[6]) || scalars[8] >= maxiter) {
-        scalars[7] = 1.0;
-        return;
-      }
+      cg_close_iteration(scalars, maxiter);
+      if (scalars[7] != 0.0) return;
     }
     if (phase == 5) {
       scalars[1] = total;
-      scalars[3] = scalars[0] / total;
-      scalars[2] = 0.0;
-      scalars[9] = 1.0;
+      cg_set_alpha(scalars, total);
+      if (scalars[7] == 0.0) scalars[9] = 1.0;
     }
     return;
   }
@@ -623,10 +659,7 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     const double total = block_sum(v);
     if (tid == 0 && scalars[7] == 0.0) {
       scalars[1] = total;
-      if (phase == 4) {             // ... and phase 0 in the same launch
-        scalars[3] = scalars[0] / total;
-        scalars[2] = 0.0;
-      }
+      if (phase == 4) cg_set_alpha(scalars, total);   // ... and phase 0
     }
     return;
   }
@@ -639,19 +672,27 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     scalars[1] = 0.0;
     scalars[2] = 0.0;
     scalars[8] = 0.0;
-    scalars[7] = (!(scalars[0] > scalars[6]) || maxiter <= 0.0) ? 1.0 : 0.0;
+    scalars[9] = 0.0;
+    scalars[10] = SFEM_CG_STATUS_RUNNING;
+    scalars[7] = 0.0;
+    if (cg_bad_gamma(scalars[0])) {
+      scalars[10] = SFEM_CG_STATUS_BAD_GAMMA;
+      scalars[7] = 1.0;
+    } else if (!(scalars[0] > scalars[6])) {
+      scalars[10] = SFEM_CG_STATUS_CONVERGED;
+      scalars[7] = 1.0;
+    } else if (maxiter <= 0.0) {
+      scalars[10] = SFEM_CG_STATUS_MAXITER;
+      scalars[7] = 1.0;
+    }
     return;
   }
   if (scalars[7] != 0.0) return;
   if (phase == 0) {
-    scalars[3] = scalars[0] / scalars[1];
-    scalars[2] = 0.0;
+    cg_set_alpha(scalars, scalars[1]);
   } else {
-    scalars[4] = scalars[2] / scalars[0];
-    scalars[0] = scalars[2];
     scalars[1] = 0.0;
-    scalars[8] += 1.0;
-    if (!(scalars[0] > scalars[6]) || scalars[8] >= maxiter) scalars[7] = 1.0;
+    cg_close_iteration(scalars, maxiter);
   }
 }
 

@@ -55,6 +55,7 @@ def _as_vec(t):
 class _Scalars:
   """Device-resident CG scalars (see include/sfem.h, SFEM_CG_NSCALARS)."""
   GAMMA, PAP, GAMMA_NEW, ALPHA, BETA, BB, ATOL2, DONE, ITERS = range(9)
+  STATUS = 10
 
   def __init__(self, device):
     self.t = torch.zeros(_lib.SFEM_CG_NSCALARS, dtype=torch.float64,
@@ -255,8 +256,17 @@ class CGRunner:
   def info(self):
     self._flush()
     scal = self.s.t.cpu()
+    status = _lib.CG_STATUS.get(int(scal[_Scalars.STATUS].item()), 'unknown')
+    if status == 'running' and self.issued >= self.maxiter:
+      status = 'maxiter'
+    # 'residual' and 'num_iterations' as the reference returns them
+    # (cg.py:96-97); 'status' says why the loop ended: 'converged', 'maxiter',
+    # or a breakdown the reference would have reported as convergence
+    # ('breakdown_gamma': r.Mr negative / not finite, 'breakdown_pAp': p.Ap
+    # not positive) -- x is then the last iterate, NOT a solution to `tol`.
     return {'residual': self.s.t[_Scalars.GAMMA].clone(),
-            'num_iterations': int(scal[_Scalars.ITERS].item())}
+            'num_iterations': int(scal[_Scalars.ITERS].item()),
+            'status': status}
 
 
 def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
@@ -287,10 +297,11 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
       `A` and `M` must then be pure device work on fixed operands.
     check_every: the host polls the device convergence flag this often.
   Returns:
-    (x, info) with info = {'residual': gamma, 'num_iterations': k}.
+    (x, info) with info = {'residual': gamma, 'num_iterations': k,
+    'status': 'converged' | 'maxiter' | 'breakdown_gamma' | 'breakdown_pAp'}.
   """
   if not _leaves(b):
-    return b, {'residual': 0.0, 'num_iterations': 0}
+    return b, {'residual': 0.0, 'num_iterations': 0, 'status': 'converged'}
   run = CGRunner(A, b, x0, tol=tol, atol=atol, maxiter=maxiter, M=M,
                  dot_fn=dot_fn, reduce_fn=reduce_fn, interface=interface)
   if graph and dot_fn is None and run.maxiter > 2 and not run.done():

@@ -15,15 +15,19 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-  """The HIP library is git-ignored: build it in-tree if this checkout has not
-  been built yet (hipcc cross-compiles gfx950 without a GPU).  The tests never
-  fall back to anything else when it is missing."""
-  lib = os.path.join(ROOT, 'swirl_fem_amd', 'libsfem_hip.so')
-  if not os.path.exists(lib):
-    import subprocess
-    subprocess.run(['make', '-C', os.path.join(ROOT, 'swirl_fem_amd', 'csrc'),
-                    '-j', str(min(8, os.cpu_count() or 1))], check=False,
-                   stdout=subprocess.DEVNULL)
+  """The HIP library is git-ignored: (re)build it in-tree before the tests --
+  `make` is an incremental no-op when the library is current, and a stale
+  library from older sources must never be what gets tested (hipcc
+  cross-compiles gfx950 without a GPU).  The tests never fall back to anything
+  else when it is missing."""
+  import subprocess
+  res = subprocess.run(['make', '-C', os.path.join(ROOT, 'swirl_fem_amd', 'csrc'),
+                        '-j', str(min(8, os.cpu_count() or 1))], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                       text=True)
+  if res.returncode != 0:
+    raise pytest.UsageError('building libsfem_hip.so failed:\n' +
+                            res.stderr[-4000:])
 
 
 @pytest.fixture(scope='session')

@@ -285,3 +285,57 @@ def test_block_plans_of_the_8_gpu_grid_are_symmetric():
   # every global node is held by someone; holders of interior nodes are unique
   allk = np.concatenate([p.global_keys for p in parts])
   assert len(np.unique(allk)) == parts[0].num_global_nodes
+
+
+def _run_bench(*flags, timeout=600):
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+  res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *flags],
+                       env=env, capture_output=True, text=True,
+                       timeout=timeout)
+  lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+  return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus 2 ...` as a plain command (no torchrun, no
+  WORLD_SIZE): the parent spawns the ranks, they meet over gloo, build their
+  blocks and exchange the interface; rank 0 prints exactly one JSON line."""
+  res, line = _run_bench('--gpus', '2', '--backend', 'gloo', '--elems', '4',
+                         '--dry-run')
+  assert res.returncode == 0, res.stderr[-2000:]
+  assert line['n_gpus'] == 2 and line['config']['world_size_seen'] == 2
+  assert line['config']['blocks'] == '2x1x1'
+  assert line['config']['dof_count_via_exchange_ok'] is True
+  assert line['config']['interface_values_sent_rank0'] == 29 * 29
+  assert sum(l.startswith('{') for l in res.stdout.splitlines()) == 1
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+  res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'),
+                        '--gpus', '2', '--dry-run'], env=env,
+                       capture_output=True, text=True, timeout=300)
+  assert res.returncode != 0
+  assert 'WORLD_SIZE=4 but --gpus 2' in (res.stderr + res.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_gpu_as_a_plain_command():
+  """The real thing on the GPU box: two ranks sharing the visible GPU (gloo
+  transport, because RCCL refuses two ranks per device), kernels running."""
+  res, line = _run_bench('--gpus', '2', '--backend', 'gloo', '--elems', '8',
+                         '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                         '--no-general')
+  assert res.returncode == 0, res.stderr[-2000:]
+  assert line['n_gpus'] == 2 and line['value'] > 0
+  assert line['config']['world_size_seen'] == 2
+  assert len(line['config']['per_rank']['apply_ms']) == 2
+  assert line['roofline']['frac'] <= 1.0

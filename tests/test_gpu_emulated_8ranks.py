@@ -223,12 +223,30 @@ def test_partitioned_cg_on_the_triply_periodic_box(monkeypatch, grid):
                  tol=1e-8, maxiter=2000,
                  reduce_fn=lambda t: mail.all_reduce(t))
     ref_err = float((x - xg[ids]).abs().max() / xg.abs().max())
-    return errs, iters, ref_err
+    # ... and at the tight tolerance, where r . QQ^T r can cancel to a
+    # NEGATIVE number (the case of gpurun_out/flaky.log: 250 iterations and a
+    # 1.7e-2 error returned as converged under the reference's stop rule).
+    # The solve must either converge or say that it broke down.
+    x, info = cg(op.linear_operator(1.0, 1.0), b_loc, M=mesh.exchange,
+                 tol=tol, maxiter=400,
+                 reduce_fn=lambda t: mail.all_reduce(t))
+    tight = (info['status'], float(info['residual']),
+             float((x - xg[ids]).abs().max() / xg.abs().max()))
+    return errs, iters, ref_err, tight
 
   results = _run_ranks(mail, rank_main)
   for r in range(mail.world):
-    errs, iters, ref_err = results[r]
+    errs, iters, ref_err, tight = results[r]
     assert max(errs) < 1e-9 and ref_err < 1e-6, results[r]
+    status, residual, err = tight
+    assert status == results[0][3][0]          # replicated scalars agree
+    assert status in ('converged', 'breakdown_gamma', 'breakdown_pAp',
+                      'maxiter'), tight
+    if status == 'converged':
+      assert residual >= 0.0 and err < 1e-8, tight
+    if status == 'breakdown_gamma':
+      assert not residual >= 0.0, tight
+    assert residual >= 0.0 or status != 'converged', tight
     assert iters == results[0][1]
     assert max(abs(i - info_g['num_iterations']) for i in iters) <= 3
 

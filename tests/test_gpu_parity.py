@@ -560,6 +560,25 @@ def test_fused_helmholtz_geometry_kinds(ndim, n, P, dtype):
       ref = _helmholtz_ref(ofes, uu, 0.4, 1.1, bmask)
       for g, o in ops.items():
         assert relerr(o.apply(dev(uu, dtype), 0.4, 1.1), ref) < tol, (mode, g)
+    # pure stiffness through the ASSEMBLED kernels: lambda0 = 0 selects the
+    # MASS=false instantiations (for structured / sheared 3D P = 8 fp64 that is
+    # helmholtz_kernel<double,8,3,true,true,1,true,false>, the kernel bench.py
+    # times), with and without the fused u . A u, scalar and component-major
+    from swirl_fem_amd import _lib
+    for nc in (1, ndim):
+      u = rng.standard_normal((mesh.num_nodes, nc))
+      uu = u[:, 0] if nc == 1 else u
+      ref = _helmholtz_ref(ofes, uu, 0.0, 1.0, bmask)
+      for g, o in ops.items():
+        ud = dev(uu, dtype) if nc == 1 else dev(u.T.copy(), dtype).t()
+        assert relerr(o.apply(ud, 0.0, 1.0), ref) < tol, (mode, g, nc)
+        parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
+                            device=ud.device)
+        got = o.apply(ud, 0.0, 1.0, dot_out=parts)
+        assert relerr(got, ref) < tol, (mode, g, nc, 'dot')
+        # u . (mask * A u): the Dirichlet rows of `ref` are zero already
+        want, scale = float((uu * ref).sum()), float(np.abs(uu * ref).sum())
+        assert abs(float(parts.sum()) - want) <= 10 * tol * scale, (mode, g)
     ul = rng.standard_normal(rp.elements.shape)
     ref = 0.2 * ofes.mass_local(ul) + ofes.stiffness_local(ul)
     for g, o in ops.items():
@@ -718,6 +737,51 @@ def test_cg_matches_oracle_iterates():
   # zero right-hand side: no iterations
   xg, ig = cg(lambda x: Ad @ x, dev(np.zeros(n)))
   assert ig['num_iterations'] == 0 and float(xg.abs().max()) == 0.0
+
+
+def test_cg_reports_breakdown_instead_of_convergence():
+  """The reference's stop rule `gamma > atol2` (linalg/cg.py:68-73) reads a
+  negative r.Mr as converged and divides by any p.Ap; here the solve stops and
+  `info['status']` says why.  SPD solves are unaffected ('converged' /
+  'maxiter', same iterates as the oracle: test_cg_matches_oracle_iterates)."""
+  from swirl_fem_amd.linalg.cg import cg
+  b = dev(1.0 + np.arange(6.0))
+  x, info = cg(lambda x: 3 * x, b)
+  assert info['status'] == 'converged' and info['num_iterations'] == 1
+  x, info = cg(lambda x: 3 * x + 0 * x.sum(), b, tol=0.0, maxiter=0)
+  assert info['status'] == 'maxiter' and info['num_iterations'] == 0
+  # negative definite operator: p.Ap < 0 at the first iteration; x stays x0
+  x0 = dev(np.full(6, 0.25))
+  x, info = cg(lambda x: -2 * x, b, x0=x0)
+  assert info['status'] == 'breakdown_pAp' and info['num_iterations'] == 0
+  np.testing.assert_array_equal(x.cpu().numpy(), x0.cpu().numpy())
+  # indefinite "preconditioner": r.Mr < 0 before the first iteration
+  x, info = cg(lambda x: 2 * x, b, M=lambda r: -r)
+  assert info['status'] == 'breakdown_gamma' and info['num_iterations'] == 0
+  assert float(info['residual']) < 0
+  # ... and one that turns negative after an iteration (M flips the sign of
+  # the second residual): the iteration is counted, then the solve stops
+  A = dev(np.diag([1.0, 2.0, 3.0, 4.0, 5.0, 6.0]))
+  calls = []
+  def flipping(r):
+    calls.append(1)
+    return r if len(calls) == 1 else -r
+  x, info = cg(lambda x: A @ x, b, M=flipping, tol=1e-12)
+  assert info['status'] == 'breakdown_gamma' and info['num_iterations'] == 1
+  # NaN from the operator
+  x, info = cg(lambda x: x * float('nan'), b)
+  assert info['status'].startswith('breakdown')
+  # the fused-dot path (one scalar launch per iteration) has the same guards
+  rp = make_case(3, 2, 4, seed=5)
+  mesh, fes, _ = spaces(rp, 4, 4, 'gll')
+  op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
+  rhs = dev(np.random.default_rng(1).standard_normal(mesh.num_nodes)) * (
+      ~mesh.physical_masks['boundary'])
+  x, info = cg(op.linear_operator(0.0, -1.0), rhs, tol=1e-10)
+  assert info['status'] == 'breakdown_pAp' and info['num_iterations'] == 0
+  assert float(x.abs().max()) == 0.0
+  x, info = cg(op.linear_operator(0.0, 1.0), rhs, tol=1e-10)
+  assert info['status'] == 'converged'
 
 
 def test_cg_with_fused_operator_dot():
