@@ -258,7 +258,30 @@ typedef struct sfem_helmholtz_args {
                           /*   0xFFFF.  The atomics are then issued in that   */
                           /*   order (values change lanes through LDS): twice */
                           /*   the lanes per 64-byte line, same sums          */
+  /* apply, 3D, P = 4..8: cluster assembly (NULL / 0 = off).  One workgroup   */
+  /* takes the <= cluster_size elements of a cluster, sums the nodes they     */
+  /* share in LDS and touches HBM once per node: plain stores for nodes held  */
+  /* by this cluster only, atomics for the cluster surface.                   */
+  const int32_t* cluster_elems;   /* (num_clusters, cluster_size) element     */
+                                  /*   ids, -1 = empty place                  */
+  const int32_t* cluster_offsets; /* (num_clusters + 1,) start of each        */
+                                  /*   cluster's table in cluster_nodes       */
+  const uint32_t* cluster_nodes;  /* tables, ascending node id per cluster:   */
+                                  /*   id | SFEM_IDX_DIRICHLET | SFEM_IDX_    */
+                                  /*   SHARED (= also held by an element      */
+                                  /*   outside the cluster); at most          */
+                                  /*   max_shared entries per cluster         */
+  int64_t num_clusters;           /* `enc` must then be in cluster form: a    */
+                                  /*   slot whose node is in the table holds  */
+                                  /*   SFEM_IDX_SHARED | DIRICHLET bit | its  */
+                                  /*   POSITION in the table, other slots     */
+                                  /*   id | DIRICHLET bit; elem_list unused   */
 } sfem_helmholtz_args;
+
+/* cluster_size and max_shared (table entries per cluster) the cluster kernels
+ * of (P, dtype) were compiled for; SFEM_EUNSUPPORTED outside P = 4..8.       */
+int sfem_helmholtz_cluster_limits(int P, int dtype, int* cluster_size,
+                                  int* max_shared);
 #define SFEM_DOT_SLOTS 1024
 
 int sfem_helmholtz_apply(const sfem_helmholtz_args* args, sfem_stream_t stream);

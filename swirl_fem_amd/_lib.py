@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsfem_hip.so')
+# SFEM_LIB: another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get('SFEM_LIB') or os.path.join(_HERE, 'libsfem_hip.so')
 ABI_VERSION = 3
 
 SFEM_F32, SFEM_F64 = 0, 1
@@ -36,6 +37,8 @@ class HelmholtzArgs(ctypes.Structure):
       ('colored', c_i32), ('lambda0', c_dbl), ('lambda1', c_dbl),
       ('node_stride', c_i64), ('comp_stride', c_i64), ('dot_out', c_ptr),
       ('shared_order', c_ptr), ('shared_stride', c_i32),
+      ('cluster_elems', c_ptr), ('cluster_offsets', c_ptr),
+      ('cluster_nodes', c_ptr), ('num_clusters', c_i64),
   ]
 
 
@@ -92,6 +95,8 @@ SIGNATURES = {
     'sfem_helmholtz_setup_multilinear': [c_ptr, c_ptr, c_i64, c_i32, c_i32,
                                          c_i32, c_ptr],
     'sfem_helmholtz_local': [ctypes.POINTER(HelmholtzArgs), c_ptr],
+    'sfem_helmholtz_cluster_limits': [c_i32, c_i32, ctypes.POINTER(c_i32),
+                                      ctypes.POINTER(c_i32)],
     'sfem_dot': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_dot_accumulate': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_dot_indexed': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64,

@@ -404,6 +404,9 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
     node_stride, comp_stride = 1, u.stride(-1)
   lst = part.get('elem_list')
   so = part.get('shared_order')
+  cl = part.get('cluster') if enc is not None else None
+  if cl is not None:
+    enc, so = cl.enc, None
   return _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),
       geo=_dptr(part.get('geo')), geo_elem=_dptr(part.get('geo_elem')),
@@ -418,11 +421,35 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       comp_stride=comp_stride,
       dot_out=_dptr(dot_out),
       shared_order=_dptr(so if enc is not None else None),
-      shared_stride=0 if so is None or enc is None else so.shape[1])
+      shared_stride=0 if so is None or enc is None else so.shape[1],
+      cluster_elems=_dptr(cl.elems if cl is not None else None),
+      cluster_offsets=_dptr(cl.offsets if cl is not None else None),
+      cluster_nodes=_dptr(cl.nodes if cl is not None else None),
+      num_clusters=0 if cl is None else cl.num_clusters)
+
+
+_CLUSTER_LIMITS = {}
+
+
+def helmholtz_cluster_limits(P, dtype):
+  """(cluster_size, max_shared) of the cluster kernels for (P, dtype), or None
+  (`sfem_helmholtz_cluster_limits`)."""
+  key = (P, dtype)
+  if key not in _CLUSTER_LIMITS:
+    size, kmax = ctypes.c_int32(0), ctypes.c_int32(0)
+    code = _lib.SFEM_F64 if dtype == torch.float64 else _lib.SFEM_F32
+    rc = _lib.load().sfem_helmholtz_cluster_limits(
+        P, code, ctypes.byref(size), ctypes.byref(kmax))
+    _CLUSTER_LIMITS[key] = None if rc else (size.value, kmax.value)
+  return _CLUSTER_LIMITS[key]
 
 
 def helmholtz_kernel_name(real, P, ndim, scalar, geo_mode, part, mass):
   """Mirror of `launch_helmholtz`'s choice (csrc/sfem_helmholtz.h)."""
+  b = lambda v: 'true' if v else 'false'
+  if part.get('cluster') is not None:
+    return 'sfem::helmholtz_cluster_kernel<%s, %d, %s, %d, %s>' % (
+        real, P, b(scalar), geo_mode, b(mass))
   tpe = P * P if ndim == 3 else P
   can_sort = ndim == 3 and tpe <= 64
   sort = (can_sort and part.get('shared_order') is not None and

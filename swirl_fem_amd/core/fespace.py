@@ -346,13 +346,14 @@ class FiniteElementSpace:
 
   # -------------------------------------------------------- fused operators
   def helmholtz_operator(self, dirichlet_mask=None, geometry='auto',
-                         assembly='atomic'):
+                         assembly='auto'):
     """Fused `out = mask * scatter((l0 B + l1 A)_local(gather(u)))`.
 
     `geometry`: 'auto' evaluates the geometric factors of affine / multilinear
     elements in registers and stores 6 factors per point only for curved
     elements; 'stored' stores them for every element (same results to
-    rounding).
+    rounding).  `assembly`: how shared nodes are summed, see
+    `operators.HelmholtzOperator.create`.
     """
     from swirl_fem_amd.core import operators
     # cached per (mask object, options); the entry keeps the mask alive so that
@@ -362,7 +363,7 @@ class FiniteElementSpace:
     hit = self._cache.get(key)
     if hit is not None and hit[0] is dirichlet_mask:
       return hit[1]
-    if not self.is_collocated and assembly == 'atomic' and (
+    if not self.is_collocated and assembly in ('auto', 'atomic') and (
         operators.supports_two_grid(self) is None):
       # quadrature != nodes: interpolate, fused element kernel on the
       # quadrature grid, transposed interpolation

@@ -95,6 +95,32 @@ def classify_geometry(fespace):
 _GEO_POINT, _GEO_AFFINE, _GEO_MULTILINEAR = 0, 1, 3
 
 
+def _cluster_limits(fespace):
+  """(cluster_size, max_shared) if the cluster kernels cover this space."""
+  mesh = fespace.mesh
+  if mesh.ndim != 3:
+    return None
+  return _ops.helmholtz_cluster_limits(mesh.gridpoints_1d.num_points,
+                                       fespace.dtype)
+
+
+def _attach_clusters(fespace, enc, multiplicity, parts):
+  """`parts` with a `ClusterPlan` each (`core/clusters.py`): every launch then
+  sums the shared nodes of 8 neighbouring elements in LDS."""
+  from swirl_fem_amd.core import clusters
+  size, kmax = _cluster_limits(fespace)
+  ids = [None if 'elem_list' not in p else p['elem_list'].to(torch.int64)
+         for p in parts]
+  plans = clusters.build_cluster_plan(fespace.mesh, enc, multiplicity, ids,
+                                      size, kmax)
+  out = []
+  for part, plan in zip(parts, plans):
+    if plan is not None:
+      out.append(dict({k: v for k, v in part.items() if k != 'shared_order'},
+                      cluster=plan))
+  return out
+
+
 @dataclasses.dataclass(eq=False)
 class HelmholtzOperator:
   fespace: object
@@ -108,17 +134,32 @@ class HelmholtzOperator:
 
   @classmethod
   def create(cls, fespace, dirichlet_mask=None, geometry='auto',
-             assembly='atomic') -> 'HelmholtzOperator':
+             assembly='auto') -> 'HelmholtzOperator':
     """geometry: 'auto' (per element: affine / multilinear / stored factors),
     'multilinear' (no affine shortcut) or 'stored' (6 factors per point for
-    every element, the general-geometry path)."""
+    every element, the general-geometry path).
+
+    assembly (direct-stiffness summation of the shared nodes):
+    'atomic': one HBM atomic per shared slot, issued in ascending node order
+    (the fastest measured: DESIGN 3.1); 'cluster': clusters of 8 elements
+    summed in LDS, HBM atomics only on the cluster surfaces (3D, P = 4..8;
+    `core/clusters.py`: half the atomic traffic, but 1.04 vs 0.78 ms at
+    config 2 -- the waves of a cluster wait for each other); 'colored': one
+    launch per conflict-free colour class, no atomics, bitwise reproducible;
+    'auto': 'atomic' (or 'cluster' with SFEM_CLUSTER=1 in the environment)."""
     why = supports_fused(fespace)
     if why is not None:
       raise NotImplementedError(f'fused Helmholtz kernel unavailable: {why}')
     if geometry not in ('auto', 'multilinear', 'stored'):
       raise ValueError(f'unknown geometry mode {geometry!r}')
-    if assembly not in ('atomic', 'colored'):
+    if assembly not in ('auto', 'cluster', 'atomic', 'colored'):
       raise ValueError(f'unknown assembly mode {assembly!r}')
+    requested = assembly
+    if assembly == 'auto':
+      assembly = ('cluster' if _cluster_limits(fespace) is not None and
+                  os.environ.get('SFEM_CLUSTER', '0') == '1' else 'atomic')
+    elif assembly == 'cluster' and _cluster_limits(fespace) is None:
+      raise NotImplementedError('cluster assembly needs ndim = 3, P = 4..8')
     mesh = fespace.mesh
     E = mesh.num_elements
     w = torch.as_tensor(fespace.quadrature.weights_nd(mesh.ndim),
@@ -186,7 +227,17 @@ class HelmholtzOperator:
       unref = torch.nonzero(plan.multiplicity == 0).reshape(-1)
       zero_range = ((int(unref.min()), int(unref.max()) + 1)
                     if unref.numel() else (0, 0))
-    if (assembly != 'colored' and mesh.ndim == 3 and
+    if assembly == 'cluster':
+      from swirl_fem_amd.core import clusters
+      why = clusters.supports_clusters(mesh, enc)
+      if why is None:
+        parts = _attach_clusters(fespace, enc, plan.multiplicity, parts)
+      elif requested == 'cluster':
+        raise NotImplementedError(f'cluster assembly unavailable: {why}')
+      else:
+        assembly = 'atomic'
+
+    if (assembly == 'atomic' and mesh.ndim == 3 and
         mesh.gridpoints_1d.num_points <= 8 and      # one wave per element
         os.environ.get('SFEM_SORTED_SCATTER', '1') != '0'):
       # 3D: most slots of an element are shared; issue their atomics in node
@@ -213,10 +264,12 @@ class HelmholtzOperator:
     E = self.enc.shape[0]
     if mask.shape != (E,):
       raise ValueError(f'expected an ({E},) element mask')
+    clustered = any(p.get('cluster') is not None for p in self.parts)
     halves = []
     for keep in (mask, ~mask):
       parts = []
       for part in self.parts:
+        part = {k: v for k, v in part.items() if k != 'cluster'}
         if 'elem_list' in part:
           lst = part['elem_list']
           lst = lst[keep[lst.to(torch.int64)]]
@@ -224,6 +277,10 @@ class HelmholtzOperator:
           lst = torch.nonzero(keep).reshape(-1).to(torch.int32)
         if lst.numel():
           parts.append(dict(part, elem_list=lst.contiguous()))
+      if clustered:     # each half clusters its own elements
+        parts = _attach_clusters(
+            self.fespace, self.enc,
+            self.fespace.mesh.assembly_plan().multiplicity, parts)
       halves.append(dataclasses.replace(self, parts=parts))
     return tuple(halves)
 

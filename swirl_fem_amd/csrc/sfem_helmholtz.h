@@ -37,6 +37,12 @@
 #pragma once
 #include "sfem_common.h"
 
+#ifndef SFEM_CL_SWIZZLE
+#define SFEM_CL_SWIZZLE 1
+#endif
+#ifndef SFEM_CL_SCOPE
+#define SFEM_CL_SCOPE "wavefront"
+#endif
 namespace sfem {
 
 template <typename T>
@@ -235,9 +241,15 @@ struct ElemGeom {
   __device__ __forceinline__ bool is_affine() const { return HAS_AFFINE; }
   __device__ __forceinline__ bool is_multi() const { return HAS_MULTI; }
 
+  // `mem`: the same DMat in memory (a kernel that takes it as its FIRST
+  // argument passes the kernarg segment): the per-lane weights and nodes are
+  // then four small cached loads instead of four 8-deep select chains
+  // (64 v_cndmask for fp64); null = select from the by-value copy.
+  template <bool MEM = false>
   __device__ __forceinline__ void init(const HelmholtzParams<T>& prm,
                                        const DMat<T, P>& dm, int64_t e,
-                                       bool active, int i, int j, int t) {
+                                       bool active, int i, int j, int t,
+                                       const DMat<T, P>* mem = nullptr) {
     int64_t slot = e;
     if (HAS_POINT && prm.geo_index) slot = active ? prm.geo_index[e] : 0;
     base = reinterpret_cast<const char*>(prm.geo) +
@@ -247,11 +259,12 @@ struct ElemGeom {
     if (GM == GEO_POINT || !active) return;
     if (HAS_AFFINE || HAS_MULTI) {
       {
-        const T wj = lane_pick<T, P>(dm.w, j);
-        wbc = DIM == 3 ? lane_pick<T, P>(dm.w, i) * wj : wj;
+        const T wj = MEM ? mem->w[j] : lane_pick<T, P>(dm.w, j);
+        wbc = DIM == 3 ? (MEM ? mem->w[i] : lane_pick<T, P>(dm.w, i)) * wj : wj;
         const T* A = prm.geo_elem + e * 24;   // A1..A7 (3D) / A1..A3 (2D)
         if (DIM == 3) {
-          const T s = lane_pick<T, P>(dm.x, i), tt = lane_pick<T, P>(dm.x, j);
+          const T s = MEM ? mem->x[i] : lane_pick<T, P>(dm.x, i);
+          const T tt = MEM ? mem->x[j] : lane_pick<T, P>(dm.x, j);
           T a0[3], a1[3], a2[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -445,6 +458,196 @@ struct ElemGeom {
     }
   }
 };
+
+// The DMat a kernel received as its FIRST argument, as memory (kernarg segment,
+// offset 0): lane-indexed reads of its weights / nodes become cached loads.
+template <typename T, int P>
+__device__ __forceinline__ const DMat<T, P>* kernarg_dmat() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (const DMat<T, P>*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  return nullptr;
+#endif
+}
+
+// Orders LDS traffic among the lanes of ONE wave: no instruction (LDS executes
+// a wave's operations in order), only a fence for the compiler.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, SFEM_CL_SCOPE);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SFEM_CL_SCOPE);
+}
+
+// Position of node (a, r, c) of an element's P^3 tensor inside its LDS copy,
+// for the three ways the kernel walks it:
+//   own(a)    lane (i, j) touches (a, i, j)      a = compile-time index
+//   last(m)   lane (i, j) touches (i, j, m)      line along the last axis
+//   mid(m)    lane (i, j) touches (i, m, j)      line along the middle axis
+// P = 8: rows are NOT padded (8 KB per fp64 element instead of 9.2: that is
+// what lets two 8-element workgroups share a CU); instead
+//   phys(a, r, c) = 64 a + 8 (r ^ (a & 3)) + (c ^ r)
+// which makes the 32 lanes of a ds_read_b64 / ds_write_b64 group hit 32
+// different 8-byte banks in all three patterns (unswizzled: 4- and 8-way
+// conflicts, the LDS pipe then bounds the kernel).  The XOR constants reduce
+// to one v_xor_b32 per access: own(a) = 64 a + L1[a & 3], last(m) = L2 ^ m,
+// mid(m) = L3 ^ 9 m.  Other P: rows padded to an odd length as before.
+template <typename T, int P>
+struct ClusterLayout {
+  static constexpr bool SWIZZLE = P == 8 && SFEM_CL_SWIZZLE;
+  static constexpr int SB = SWIZZLE ? P : (P | 1);
+  static constexpr int SA = P * SB;
+  static constexpr int WORDS = P * SA;
+  static constexpr int S = (int)sizeof(T);
+  // BYTE offsets from the start of the workgroup's LDS array (which is 512-byte
+  // aligned, as is every element's pair of copies: the XORs below then never
+  // reach the bits of the base and one v_xor_b32 per access is all it costs)
+  char* lds;
+  uint32_t b1[SWIZZLE ? 4 : 1], b2, b3;
+  __device__ __forceinline__ void init(T* lds_base, int el, int i, int j) {
+    lds = reinterpret_cast<char*>(lds_base);
+    const uint32_t base = (uint32_t)el * 2 * WORDS * S;   // s0; s1 = + WORDS*S
+    if (SWIZZLE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        b1[q] = base + S * (((i ^ q) << 3) + (j ^ i));
+      b2 = base + WORDS * S + S * ((i << 6) + ((j ^ (i & 3)) << 3) + j);
+      b3 = base + S * ((i << 6) + ((i & 3) << 3) + j);
+    } else {
+      b1[0] = base + S * (i * SB + j);
+      b2 = base + WORDS * S + S * (i * SA + j * SB);
+      b3 = base + S * (i * SA + j);
+    }
+  }
+  __device__ __forceinline__ T& at(uint32_t off) const {
+    return *reinterpret_cast<T*>(lds + off);
+  }
+  // copy 0 / copy 1 at the lane's own node of slice a
+  __device__ __forceinline__ T& own0(int a) const {
+    return at(SWIZZLE ? b1[a & 3] + a * 64 * S : b1[0] + a * SA * S);
+  }
+  __device__ __forceinline__ T& own1(int a) const {
+    return at((SWIZZLE ? b1[a & 3] + a * 64 * S : b1[0] + a * SA * S) +
+              WORDS * S);
+  }
+  // copy 1 along the last axis, copy 0 along the middle axis
+  __device__ __forceinline__ T& last1(int m) const {
+    return at(SWIZZLE ? (b2 ^ (uint32_t)(m * S)) : b2 + m * S);
+  }
+  __device__ __forceinline__ T& mid0(int m) const {
+    return at(SWIZZLE ? (b3 ^ (uint32_t)(9 * m * S)) : b3 + m * SB * S);
+  }
+};
+
+// (lambda0 B + lambda1 A)_local of one element held by (part of) one wave:
+// ua[a] = nodal values of the lane's line, acc[a] = result.  s0 / s1: the
+// element's two LDS copies.  Same arithmetic as helmholtz_kernel.
+template <typename T, int P, int GM, bool MASS>
+__device__ __forceinline__ void cluster_element_apply(
+    const HelmholtzParams<T>& prm, const DMat<T, P>& dm,
+    const ElemGeom<T, P, 3, GM>& geom, const ClusterLayout<T, P>& lay,
+    bool lane_ok, bool active, const T (&ua)[P], T (&acc)[P]) {
+  const bool has_stiff = prm.lambda1 != T(0);
+  if (has_stiff) {
+    T d0[P];
+    line_apply<T, P, false>(dm, ua, d0);
+    if (lane_ok) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        lay.own0(a) = ua[a];
+        lay.own1(a) = ua[a];
+      }
+    }
+    wave_sync();
+    if (lane_ok) {   // last axis: the line [i, j, *]
+      T x[P], y[P];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = lay.last1(m);
+      line_apply<T, P, false>(dm, x, y);
+#pragma unroll
+      for (int m = 0; m < P; ++m) lay.last1(m) = y[m];
+    }
+    if (lane_ok) {   // middle axis: the line [i, *, j]
+      T x[P], y[P];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = lay.mid0(m);
+      line_apply<T, P, false>(dm, x, y);
+#pragma unroll
+      for (int m = 0; m < P; ++m) lay.mid0(m) = y[m];
+    }
+    wave_sync();
+    T w0[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) { w0[a] = T(0); acc[a] = T(0); }
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        T& r0 = lay.own0(a);
+        T& r1 = lay.own1(a);
+        T G[6], Wm;
+        constexpr bool FUSE_W = GM != GEO_POINT;
+        if constexpr (GM == GEO_MULTILINEAR) {
+          T o0, o1, o2;
+          geom.apply_multilinear3(dm, a, MASS, d0[a], r0, r1, o0, o1, o2, Wm);
+          if (MASS) acc[a] = prm.lambda0 * Wm * ua[a];
+          w0[a] = o0; r0 = o1; r1 = o2;
+          continue;
+        }
+        geom.factors(dm, a, true, FUSE_W && MASS, G, Wm);
+        if (FUSE_W && MASS) acc[a] = prm.lambda0 * Wm * ua[a];
+        const T g0 = d0[a], g1 = r0, g2 = r1;
+        w0[a] = G[0] * g0 + G[1] * g1 + G[2] * g2;
+        r0 = G[1] * g0 + G[3] * g1 + G[4] * g2;
+        r1 = G[2] * g0 + G[4] * g1 + G[5] * g2;
+      }
+    }
+    wave_sync();
+    if (lane_ok) {   // transposed derivative along the last axis, in place
+      T x[P], y[P];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = lay.last1(m);
+      line_apply<T, P, true>(dm, x, y);
+#pragma unroll
+      for (int m = 0; m < P; ++m) lay.last1(m) = y[m];
+    }
+    if (lane_ok) {
+      T x[P], y[P];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = lay.mid0(m);
+      line_apply<T, P, true>(dm, x, y);
+#pragma unroll
+      for (int m = 0; m < P; ++m) lay.mid0(m) = y[m];
+    }
+    T dt0[P];
+    line_apply<T, P, true>(dm, w0, dt0);
+    wave_sync();
+    if (lane_ok) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        acc[a] += prm.lambda1 * (dt0[a] + lay.own0(a) + lay.own1(a));
+      }
+    }
+    wave_sync();   // the copies are free again (next component)
+    if (GM == GEO_POINT && MASS && active) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        T G[6], Wm;
+        geom.factors(dm, a, false, true, G, Wm);
+        acc[a] += prm.lambda0 * Wm * ua[a];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < P; ++a) acc[a] = T(0);
+    if (MASS && active) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        T G[6], Wm;
+        geom.factors(dm, a, false, true, G, Wm);
+        acc[a] = prm.lambda0 * Wm * ua[a];
+      }
+    }
+  }
+}
 
 // Second half of the sorted shared scatter (see helmholtz_kernel): the lanes of
 // one element walk its SHARED slots in ascending node order; `vals` is the

@@ -2,7 +2,7 @@
 // setup kernels (symmetric geometric factors, encoded indices).
 #include <stdlib.h>
 
-#include "sfem_helmholtz.h"
+#include "sfem_helmholtz_cluster.h"
 
 namespace sfem {
 
@@ -123,6 +123,10 @@ struct HelmholtzCall {
   int64_t node_stride, comp_stride;
   const uint16_t* shared_order = nullptr;
   int shared_stride = 0;
+  const int32_t* cluster_elems = nullptr;
+  const int32_t* cluster_offsets = nullptr;
+  const uint32_t* cluster_nodes = nullptr;
+  int64_t num_clusters = 0;
 };
 
 template <typename T>
@@ -141,6 +145,11 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
   prm.colored = c.colored;
   prm.shared_order = c.shared_order;
   prm.shared_stride = c.shared_stride;
+  if (c.cluster_elems) {
+    ClusterParams<T> cl{c.cluster_elems, c.cluster_offsets, c.cluster_nodes,
+                        c.num_clusters};
+    return dispatch_helmholtz_cluster<T>(prm, cl, c.P, stream);
+  }
   if (c.ndim == 3) return dispatch_helmholtz<T, 3>(prm, c.P, c.gs, stream);
   if (c.ndim == 2) return dispatch_helmholtz<T, 2>(prm, c.P, c.gs, stream);
   set_error("helmholtz: ndim=%d (fused kernel supports 2 and 3)", c.ndim);
@@ -261,8 +270,36 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   SFEM_REQUIRE(!a->shared_order || (a->shared_stride > 0 &&
                                     a->shared_stride <= 0xFFFF),
                "sfem_helmholtz_apply: bad shared_stride");
+  if (a->cluster_elems) {
+    SFEM_REQUIRE(a->ndim == 3 && a->P >= 4 && a->P <= 8,
+                 "sfem_helmholtz_apply: cluster assembly is 3D, P = 4..8");
+    SFEM_REQUIRE(a->cluster_offsets && a->cluster_nodes && a->num_clusters > 0,
+                 "sfem_helmholtz_apply: incomplete cluster description");
+    SFEM_REQUIRE(!a->colored && !a->shared_order,
+                 "sfem_helmholtz_apply: clusters exclude colored / "
+                 "shared_order");
+    c.cluster_elems = a->cluster_elems;
+    c.cluster_offsets = a->cluster_offsets;
+    c.cluster_nodes = a->cluster_nodes;
+    c.num_clusters = a->num_clusters;
+  }
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
+}
+
+int sfem_helmholtz_cluster_limits(int P, int dtype, int* cluster_size,
+                                  int* max_shared) {
+  SFEM_REQUIRE(cluster_size && max_shared,
+               "sfem_helmholtz_cluster_limits: null pointer");
+  int rc;
+  if (dtype == SFEM_F64) rc = cluster_limits<double>(P, cluster_size, max_shared);
+  else if (dtype == SFEM_F32) rc = cluster_limits<float>(P, cluster_size, max_shared);
+  else {
+    set_error("sfem_helmholtz_cluster_limits: unknown dtype %d", dtype);
+    return SFEM_EINVAL;
+  }
+  if (rc) set_error("sfem_helmholtz_cluster_limits: P=%d outside 4..8", P);
+  return rc;
 }
 
 int sfem_helmholtz_setup_multilinear(const void* elem_coords, void* geo_elem,

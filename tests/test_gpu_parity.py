@@ -588,6 +588,91 @@ def test_fused_helmholtz_geometry_kinds(ndim, n, P, dtype):
                     ofes.mass_local(ul)) < tol, (mode, g)
 
 
+@pytest.mark.parametrize('n,P,scramble', [(4, 4, False), (3, 5, True),
+                                          (3, 6, False), (2, 7, True),
+                                          (4, 8, False), (3, 8, True)])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_fused_helmholtz_cluster_assembly(n, P, scramble, dtype):
+  """Cluster assembly (`helmholtz_cluster_kernel`: shared nodes of 8 elements
+  summed in LDS, atomics on the cluster surfaces only) vs the oracle, next to
+  the one-atomic-per-slot and the coloured assembly of the same operator:
+  every geometry kind, mass on / off, 1 and 3 components (row- and
+  component-major), fused u . A u, odd element counts (clusters with empty
+  places) and scrambled element order (clusters found by bisection)."""
+  from swirl_fem_amd import _lib
+  from swirl_fem_amd.core import operators
+  rp = make_case(3, n, P, seed=41 + P, scramble=scramble)
+  rng = np.random.default_rng(43)
+  mesh, fes, ofes = spaces(rp, P, P, 'gll', dtype)
+  bmask = mesh.physical_masks['boundary'].cpu().numpy()
+  tol = 1e-10 if dtype == torch.float64 else 3e-5
+  for geometry in ('auto', 'stored'):
+    ops = {a: operators.HelmholtzOperator.create(
+        fes, mesh.physical_masks['boundary'], geometry, a)
+           for a in ('cluster', 'atomic')}
+    assert all(p.get('cluster') is not None for p in ops['cluster'].parts)
+    assert all(p.get('cluster') is None for p in ops['atomic'].parts)
+    plan = ops['cluster'].parts[0]['cluster']
+    assert plan.num_complete > 0
+    assert plan.num_surface > 0 or plan.num_clusters == 1
+    assert 'helmholtz_cluster_kernel' in ops['cluster'].kernel_name()
+    for l0, l1 in ((0.0, 1.0), (0.6, 1.3), (1.0, 0.0)):
+      for nc in (1, 3):
+        u = rng.standard_normal((mesh.num_nodes, nc))
+        uu = u[:, 0] if nc == 1 else u
+        ref = _helmholtz_ref(ofes, uu, l0, l1, bmask)
+        for layout in ('rows', 'components'):
+          if nc == 1 and layout == 'components':
+            continue
+          ud = (dev(uu, dtype) if layout == 'rows'
+                else dev(u.T.copy(), dtype).t())
+          got = {a: o.apply(ud, l0, l1) for a, o in ops.items()}
+          for a, g in got.items():
+            assert relerr(g, ref) < tol, (geometry, a, l0, nc, layout)
+          assert relerr(got['cluster'], got['atomic'].cpu().numpy()) < (
+              1e-12 if dtype == torch.float64 else 1e-5)
+          parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
+                              device=ud.device)
+          g = ops['cluster'].apply(ud, l0, l1, dot_out=parts)
+          assert relerr(g, ref) < tol
+          want, scale = float((uu * ref).sum()), float(np.abs(uu * ref).sum())
+          assert abs(float(parts.sum()) - want) <= 10 * tol * scale
+  # the two halves of a split operator cluster their own elements
+  op = operators.HelmholtzOperator.create(fes, mesh.physical_masks['boundary'],
+                                          assembly='cluster')
+  pick = torch.as_tensor(rng.random(mesh.num_elements) < 0.3, device=DEV)
+  a, b = op.split(pick)
+  u = rng.standard_normal(mesh.num_nodes)
+  out = a.apply(dev(u, dtype), 0.2, 1.0)
+  b.apply(dev(u, dtype), 0.2, 1.0, out=out, zero=False)
+  assert relerr(out, _helmholtz_ref(ofes, u, 0.2, 1.0, bmask)) < tol
+
+
+def test_cluster_assembly_on_partition_padded_elements():
+  """Uneven partitions pad the element list with all -1 rows
+  (premesh_test.py:309-317): such elements join no cluster."""
+  from swirl_fem_amd.core import operators
+  P = 4
+  pm = unit_cube_mesh(3, ndim=3)
+  pm = pm.replace(partitions=(np.arange(27) >= 10).astype(np.int32))  # 10 | 17
+  rp = refine_premesh(pm, Nodes1D.create(P, NT['gll']))
+  rng = np.random.default_rng(5)
+  for rank in (0, 1):
+    mesh = rp.finalize('i', rank=rank, device=DEV)
+    el = mesh.elements.cpu().numpy()
+    fes = FiniteElementSpace.create(
+        mesh, Quadrature1D.create_from_nodes_1d(rp.gridpoints_1d))
+    ops = {a: operators.HelmholtzOperator.create(fes, None, 'auto', a)
+           for a in ('cluster', 'atomic')}
+    u = dev(rng.standard_normal(mesh.num_nodes))
+    got = {a: o.apply(u, 0.5, 1.0) for a, o in ops.items()}
+    assert relerr(got['cluster'], got['atomic'].cpu().numpy()) < 1e-12
+    real = int((el >= 0).any(axis=1).sum())
+    assert real == (10, 17)[rank] and len(el) == 17
+    plan = ops['cluster'].parts[0]['cluster']
+    assert int((plan.elems >= 0).sum()) == real
+
+
 @pytest.mark.parametrize('ndim,n,P,scramble', [(3, 4, 4, False), (3, 3, 5, True),
                                                (2, 6, 4, True), (3, 2, 8, False)])
 def test_fused_helmholtz_colored_assembly(ndim, n, P, scramble):

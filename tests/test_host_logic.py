@@ -529,3 +529,152 @@ def test_shared_slot_order_lists_shared_slots_by_node():
     assert (got[e, len(want):] == 0xFFFF).all()
   none = torch.from_numpy((ids & 0x3FFFFFFF).astype(np.int32))
   assert shared_slot_order(none) is None
+
+
+def _encode_numpy(elements, dirichlet):
+  """What `sfem_encode_elements` produces, in NumPy."""
+  el = np.asarray(elements, dtype=np.int64)
+  valid = el >= 0
+  mult = np.bincount(el[valid], minlength=len(dirichlet))
+  code = np.where(valid, el, 0x3FFFFFFF)
+  safe = np.where(valid, el, 0)
+  code = np.where(valid & (mult[safe] > 1), code | 0x40000000, code)
+  code = np.where(valid & dirichlet[safe], code | 0x80000000, code)
+  code = np.where(valid, code, 0xFFFFFFFF)
+  return code.astype(np.uint32).view(np.int32), mult
+
+
+def _emulate_cluster_assembly(plan, loc, num_nodes, rim):
+  """The scatter stage of `helmholtz_cluster_kernel` in NumPy: element-interior
+  slots are stored, shared slots summed per cluster in a strip, complete nodes
+  stored, surface nodes added ("atomically") to the zero-filled output."""
+  enc = plan.enc.numpy().view(np.uint32).astype(np.int64)
+  nodes = plan.nodes.numpy().view(np.uint32).astype(np.int64)
+  off = plan.offsets.numpy()
+  out = np.zeros(num_nodes)
+  written = np.zeros(num_nodes, dtype=int)        # plain stores per node
+  for c, row in enumerate(plan.elems.numpy()):
+    K = off[c + 1] - off[c]
+    strip = np.zeros(K)
+    for e in row[row >= 0]:
+      for slot, code in enumerate(enc[e]):
+        ident = code & 0x3FFFFFFF
+        assert not code & 0x40000000            # cluster form has no flag
+        dirichlet = bool(code & 0x80000000)
+        if rim[slot]:
+          assert ident < K
+          if not dirichlet:
+            strip[ident] += loc[e, slot]
+        else:
+          out[ident] = 0.0 if dirichlet else loc[e, slot]
+          written[ident] += 1
+    for q in range(K):
+      code = nodes[off[c] + q]
+      ident, dirichlet = code & 0x3FFFFFFF, bool(code & 0x80000000)
+      if code & 0x40000000:
+        if not dirichlet:
+          out[ident] += strip[q]
+      else:
+        out[ident] = 0.0 if dirichlet else strip[q]
+        written[ident] += 1
+  return out, written
+
+
+@pytest.mark.parametrize('case', ['structured', 'scrambled', 'padded',
+                                  'two_parts', 'tiny_limit'])
+def test_cluster_plan_assembles_like_scatter(case):
+  """`core/clusters.py`: clusters of 8 elements, per-cluster shared-node tables
+  (ascending ids, DIRICHLET / still-SHARED flags), cluster-form index rows.
+  A NumPy walk through the kernel's bookkeeping must reproduce
+  mask * scatter(local) of the oracle (reference gather_scatter.py:130-133),
+  every node stored at most once, and every table entry must name the node
+  its slots referred to."""
+  from swirl_fem_amd.core import clusters
+  rng = np.random.default_rng(3)
+  P, nel = 4, 4
+  pm = unit_cube_mesh(nel, ndim=3)
+  rp = refine_premesh(pm, I.Nodes1D.create(P, I.NodeType.GAUSS_LOBATTO_LEGENDRE))
+  elements = np.asarray(rp.elements).copy()
+  if case == 'scrambled':
+    elements = elements[rng.permutation(len(elements))]
+  if case == 'padded':          # uneven partitions pad with all -1 elements
+    elements = np.concatenate([elements[:37], -np.ones((3, P ** 3), int),
+                               elements[37:50]])
+  E, n = elements.shape
+  N = rp.num_nodes
+  dirichlet = np.zeros(N, dtype=bool)
+  dirichlet[np.unique(rp.physical_groups['boundary'])] = True
+  enc_np, mult = _encode_numpy(elements, dirichlet)
+  mesh = Mesh.create(node_coords=rp.node_coords, elements=elements,
+                     gridpoints_1d=rp.gridpoints_1d, device='cpu')
+  enc = torch.from_numpy(enc_np.reshape(E, n))
+  mult_t = torch.from_numpy(mult.astype(np.int32))
+  ids = [None]
+  if case == 'two_parts':       # two geometry kinds = two launches
+    pick = rng.random(E) < 0.4
+    ids = [torch.from_numpy(np.nonzero(pick)[0]),
+           torch.from_numpy(np.nonzero(~pick)[0])]
+  kmax = 150 if case == 'tiny_limit' else 448
+  assert clusters.supports_clusters(mesh, enc) is None
+  plans = clusters.build_cluster_plan(mesh, enc, mult_t, ids, 8, kmax)
+  rim = clusters.lattice_boundary_slots(P, 3, 'cpu').numpy()
+  assert rim.sum() == P ** 3 - (P - 2) ** 3
+  loc = rng.standard_normal((E, n))
+  out = np.zeros(N)
+  written = np.zeros(N, dtype=int)
+  real = (elements >= 0).any(axis=1)
+  seen = np.zeros(E, dtype=int)
+  for plan in plans:
+    o, w = _emulate_cluster_assembly(plan, loc, N, rim)
+    out += o
+    written += w
+    assert plan.max_shared <= kmax
+    el = plan.elems.numpy()
+    np.add.at(seen, el[el >= 0], 1)
+    # tables: ascending node ids per cluster, flags as documented
+    nodes = plan.nodes.numpy().view(np.uint32).astype(np.int64)
+    off = plan.offsets.numpy()
+    cenc = plan.enc.numpy().view(np.uint32).astype(np.int64)
+    for c, row in enumerate(el):
+      tab = nodes[off[c]:off[c + 1]] & 0x3FFFFFFF
+      assert (np.diff(tab) > 0).all()
+      inside = np.bincount(elements[row[row >= 0]].reshape(-1), minlength=N)
+      surf = (nodes[off[c]:off[c + 1]] & 0x40000000) != 0
+      np.testing.assert_array_equal(surf, inside[tab] < mult[tab])
+      np.testing.assert_array_equal(
+          (nodes[off[c]:off[c + 1]] & 0x80000000) != 0, dirichlet[tab])
+      for e in row[row >= 0]:
+        np.testing.assert_array_equal(tab[cenc[e][rim] & 0x3FFFFFFF],
+                                      elements[e][rim])
+        np.testing.assert_array_equal(cenc[e][~rim] & 0x3FFFFFFF,
+                                      elements[e][~rim])
+  np.testing.assert_array_equal(seen, real.astype(int))   # each element once
+  assert written.max() <= 1
+  ref = O.scatter(np.where(elements >= 0, loc, 0.0), elements, N)
+  ref = ref * ~dirichlet
+  np.testing.assert_allclose(out, ref, rtol=0, atol=1e-13)
+  if case == 'structured':
+    # 4^3 elements, P = 4: RCB leaves are the eight 2x2x2 blocks
+    plan = plans[0]
+    assert plan.num_clusters == 8 and (plan.elems.numpy() >= 0).all()
+    sizes = np.diff(plan.offsets.numpy())
+    # 7^3 nodes - 8 * 2^3 lattice-interior ones
+    assert (sizes == 7 ** 3 - 8 * 2 ** 3).all()
+    cent = rp.node_coords[elements[plan.elems.numpy()][:, :, 0]]
+    assert (np.ptp(cent, axis=1) <= 0.25 + 1e-12).all()  # compact blocks
+  if case == 'tiny_limit':
+    assert plans[0].num_clusters > 8                      # clusters were split
+
+
+def test_rcb_order_groups():
+  from swirl_fem_amd.core import clusters
+  rng = np.random.default_rng(1)
+  for M, leaf in [(1, 8), (7, 8), (8, 8), (9, 8), (100, 8), (64, 4), (27, 8)]:
+    x = torch.from_numpy(rng.random((M, 3)))
+    perm, group = clusters.rcb_order(x, leaf)
+    assert sorted(perm.tolist()) == list(range(M))
+    g = group.numpy()
+    assert (np.diff(g) >= 0).all() and g[0] == 0
+    counts = np.bincount(g)
+    assert counts.max() <= leaf and len(counts) == g[-1] + 1
+    assert len(counts) <= -(-M // leaf) + max(0, int(np.log2(max(M, 2))))
