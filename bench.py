@@ -75,24 +75,24 @@ def block_grid(world):
       world, (world, 1, 1))
 
 
-def cpu_baseline(P, budget_s=12.0):
+def cpu_baseline(P, budget_s=12.0, ne=32):
   """Times the reference algorithm on this host's cores: dense Kronecker
   element matrices, 9+1 stored geometric arrays, un-fused CG
   (`oracle/cpu_reference.py`, the oracle's algorithm with the element-batch
-  contractions as multi-threaded torch-CPU GEMMs), on a bounded 10^3-element
-  sample of the same p=7 Dirichlet Laplacian."""
+  contractions as multi-threaded torch-CPU GEMMs), on a bounded sample of the
+  same Dirichlet Laplacian: 32^3 elements ("32^3 if 64^3 does not
+  fit"; the reference's array layout needs 25 GB at 64^3), as many CG
+  iterations as fit `budget_s` seconds (at least 3)."""
   import torch
   from oracle import cpu_reference
   from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
   from swirl_fem_amd.core.interpolation import Nodes1D, NodeType
   from swirl_fem_amd.core.mesh_refiner import refine_premesh
-  ne = 10
   rp = refine_premesh(unit_cube_mesh(ne, ndim=3),
                       Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE))
   mask = np.zeros(rp.num_nodes)
   mask[np.unique(rp.physical_groups['boundary'])] = 1.0
-  # the GPU box shares its host: a rank gets about 16 cores, and the small
-  # GEMMs of this sample slow down when spread over every hardware thread
+  # the GPU box shares its host: a rank gets about 16 cores
   saved = torch.get_num_threads()
   torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
   try:
@@ -525,7 +525,7 @@ def main():
                     'reads its %d factors per point, as curved elements do '
                     '(= the SURVEY 8(d) byte model)' % ngeo}
     if world == 1 and not args.no_cpu_baseline:
-      res['cpu_baseline'] = cpu_baseline(P)
+      res['cpu_baseline'] = cpu_baseline(P, ne=min(32, args.n) if args.p <= 7 else min(12, args.n))
     else:
       res['cpu_baseline'] = None
     print(json.dumps(res))

@@ -9,9 +9,9 @@ file per cycle holding the datasets `t (S,)`, `u (S, N, 2)`, `p (S, Np)`
 `DatagenConfig`; the time step itself is
 `examples.navier_stokes_driver.navier_stokes_step`.
 
-Snapshots go to HDF5 when `h5py` is importable (the reference's container,
-same dataset names and shapes); without it the same three arrays are written
-as a NumPy `.npz` archive -- the file suffix says which.
+Snapshots are HDF5 files with the reference's layout (datasets 't', 'u', 'p'
+at the root; same names and shapes), written through `h5py` when it is
+importable and through the HDF5 C library otherwise (`h5lite`).
 """
 
 from __future__ import annotations
@@ -88,21 +88,52 @@ def _solve_one_step(sem, us, ps, Cus, cfg: DatagenConfig):
   return u, p, Cu
 
 
-def write_snapshots(path_stem: str, dataset: dict) -> str:
-  """Writes `{'t', 'u', 'p'}`; returns the path of the file written."""
+def write_snapshots(path_stem: str, dataset: dict, format: str = 'hdf5') -> str:
+  """Writes `{'t', 'u', 'p'}` as `<path_stem>.hdf5`, the reference's container
+  (:127-165: one dataset per key at the root of the file); returns the path.
+
+  HDF5 goes through `h5py` when it is importable, else through the HDF5 C
+  library (`h5lite`, ctypes).  If neither is present this raises -- a dataset
+  silently written in another container would break its readers.
+  `format='npz'` asks for a NumPy archive explicitly.
+  """
+  if format == 'npz':
+    path = path_stem + '.npz'
+    np.savez(path, **dataset)
+    return path
+  if format != 'hdf5':
+    raise ValueError(f'unknown snapshot format {format!r}')
+  path = path_stem + '.hdf5'
   try:
     import h5py                      # pylint: disable=import-outside-toplevel
   except ImportError:
     h5py = None
   if h5py is not None:
-    path = path_stem + '.hdf5'
     with h5py.File(path, 'w') as f:
       for k, v in dataset.items():
         f[k] = v
     return path
-  path = path_stem + '.npz'
-  np.savez(path, **dataset)
+  from swirl_fem_amd.niles.datagen import h5lite
+  if not h5lite.available():
+    raise ImportError(
+        'writing HDF5 snapshots needs h5py or the HDF5 C library (libhdf5); '
+        "neither was found -- pass format='npz' for a NumPy archive instead")
+  h5lite.write(path, {k: np.asarray(v) for k, v in dataset.items()})
   return path
+
+
+def read_snapshots(path: str) -> dict:
+  """Reads a file written by `write_snapshots` back into NumPy arrays."""
+  if path.endswith('.npz'):
+    with np.load(path) as z:
+      return {k: z[k] for k in z.files}
+  try:
+    import h5py                      # pylint: disable=import-outside-toplevel
+  except ImportError:
+    from swirl_fem_amd.niles.datagen import h5lite
+    return h5lite.read(path)
+  with h5py.File(path, 'r') as f:
+    return {k: np.asarray(f[k]) for k in f}
 
 
 def one_cycle(sem, start_step: int, num_steps: int, us, ps, *,

@@ -149,6 +149,44 @@ def _router_worker(rank, world, port, results):
     assert int(pscan(torch.tensor([rank]), 'maximum')) == (
         rank - 1 if rank else torch.iinfo(torch.int64).min)
     assert int(preduce(torch.tensor([rank]), 'maximum')) == world - 1
+    # the reference's seven monoids (pscan.py:42-51), by name and by function
+    ranks = np.arange(world)
+    vals = (3 * ranks + 1).astype(np.int64)           # 1, 4, 7, ...
+    mine = torch.tensor([int(vals[rank]), int(vals[rank]) ^ 5])
+    both = np.stack([vals, vals ^ 5], axis=1)
+    for name, fn, unit in (('multiply', np.multiply, 1),
+                           ('minimum', np.minimum, np.iinfo(np.int64).max),
+                           ('bitwise_and', np.bitwise_and, -1),
+                           ('bitwise_or', np.bitwise_or, 0),
+                           ('bitwise_xor', np.bitwise_xor, 0)):
+      want = np.full(2, unit, dtype=np.int64)
+      for r in range(rank):
+        want = fn(want, both[r])
+      total = np.full(2, unit, dtype=np.int64)
+      for r in range(world):
+        total = fn(total, both[r])
+      ex, tot = pscan(mine, name, reduction=True)
+      assert ex.tolist() == want.tolist(), (name, ex, want)
+      assert tot.tolist() == total.tolist(), name
+      assert preduce(mine, getattr(torch, name)).tolist() == total.tolist()
+    flags = torch.tensor([rank % 2 == 0, rank == 1])
+    assert pscan(flags, 'bitwise_or').tolist() == [rank > 0, rank > 1]
+    assert preduce(flags, torch.bitwise_and).tolist() == [world == 1, False]
+    # pytrees: mapped over the leaves, structure preserved (pscan.py:225-241)
+    tree = {'n': torch.tensor([rank + 1]),
+            'x': (torch.tensor([0.5 * (rank + 1)], dtype=torch.float64),
+                  [torch.tensor([[rank, 1]], dtype=torch.int32)])}
+    ex, tot = pscan(tree, torch.add, axis_name='parts', reduction=True)
+    tri = rank * (rank + 1) // 2
+    assert int(ex['n']) == tri and float(ex['x'][0]) == 0.5 * tri
+    assert ex['x'][1][0].tolist() == [[rank * (rank - 1) // 2, rank]]
+    assert ex['x'][1][0].dtype == torch.int32 and isinstance(ex['x'], tuple)
+    assert int(tot['n']) == world * (world + 1) // 2
+    assert preduce(tree, 'maximum')['x'][1][0].tolist() == [[world - 1, 1]]
+    with pytest.raises(ValueError):
+      pscan(mine, 'subtract')
+    with pytest.raises(TypeError):
+      pscan(torch.tensor([1.0]), 'bitwise_or')
     # neighbour discovery == the block builder's lattice-based plan
     grid = {2: (2, 1, 1), 3: (3, 1), 4: (2, 2, 1), 5: (5, 1)}[world]
     part = blocks.build_block_partition(2, 3, grid, rank, device='cpu')

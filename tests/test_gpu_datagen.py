@@ -25,13 +25,10 @@ def test_kolmogorov_cycle_snapshots(tmp_path):
   assert [n.rsplit('.', 1)[0] for n in names] == [stem + '0_20', stem + '20_40']
   assert [os.path.join(tmp_path, n) for n in names] == sorted(paths)
 
-  def load(path):
-    if path.endswith('.npz'):
-      with np.load(path) as f:
-        return {k: f[k] for k in f.files}
-    import h5py
-    with h5py.File(path, 'r') as f:
-      return {k: np.asarray(f[k]) for k in f}
+  assert all(p.endswith('.hdf5') for p in paths)       # the reference's format
+  with open(sorted(paths)[0], 'rb') as fh:
+    assert fh.read(8) == b'\x89HDF\r\n\x1a\n'            # HDF5 signature
+  load = datagen.read_snapshots
 
   sem = datagen.create_sem(cfg, DEV)
   Nv = sem.velocity.mesh.num_nodes

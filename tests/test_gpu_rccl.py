@@ -96,3 +96,40 @@ def test_partitioned_cg_over_rccl_equals_plain_cg(rccl):
     assert 0 < info['num_iterations'] < 2000
   ov = solver.OverlappedHelmholtz(op, plan, 0.2, 1.0)
   assert 0 < ov.num_boundary_elements < mesh.num_elements
+
+
+def test_router_pscan_and_discovery_over_rccl(rccl):
+  """`communication/` and `distributed/discover.py` through RCCL itself (one
+  rank): the sparse all-to-all degenerates to a permutation to self, the scans
+  to their units, and the discovered plan of a mesh that is periodic onto
+  itself is empty of remote neighbours -- every call runs on device tensors
+  over the nccl backend (the multi-rank behaviour is covered over gloo in
+  tests/test_distributed_cpu.py)."""
+  from swirl_fem_amd.communication.crystal_router import crystal_router
+  from swirl_fem_amd.communication.pscan import preduce, pscan
+  from swirl_fem_amd.distributed import blocks
+  from swirl_fem_amd.distributed.discover import discover_neighbors
+  g = torch.Generator(device=DEV).manual_seed(3)
+  n = 37
+  payload = torch.randint(0, 10 ** 6, (n, 3), device=DEV, generator=g)
+  tag = torch.arange(n, device=DEV)
+  target = torch.zeros(n, dtype=torch.int64, device=DEV)
+  n_out, (pay_o, tag_o), src = crystal_router(None, [payload, tag], target)
+  assert n_out == n and bool((src == 0).all())
+  order = torch.argsort(tag_o)
+  assert torch.equal(pay_o[order], payload) and pay_o.is_cuda
+  x = torch.tensor([5, 7], dtype=torch.int64, device=DEV)
+  ex, tot = pscan(x, 'add', reduction=True)
+  assert ex.tolist() == [0, 0] and tot.tolist() == [5, 7] and ex.is_cuda
+  for name, unit in (('multiply', 1), ('bitwise_and', -1), ('bitwise_xor', 0),
+                     ('minimum', torch.iinfo(torch.int64).max)):
+    ex, tot = pscan(x, name, reduction=True)
+    assert ex.tolist() == [unit, unit] and tot.tolist() == [5, 7], name
+  tree = {'a': torch.tensor([1.5], dtype=torch.float64, device=DEV),
+          'b': [torch.tensor([True, False], device=DEV)]}
+  red = preduce(tree, 'maximum')
+  assert float(red['a']) == 1.5 and red['b'][0].tolist() == [True, False]
+  assert float(preduce(tree['a'], torch.add)) == 1.5
+  part = blocks.build_block_partition(2, 3, (1, 1, 1), 0, device=DEV)
+  plan = discover_neighbors(part.global_keys, device=DEV)
+  assert plan.neighbors == [] and plan.num_shared == 0

@@ -171,3 +171,37 @@ def test_partition_unit_cube(num_partitions):
   arrays = refine_premesh(part, Nodes1D.create(
       3, NodeType.GAUSS_LOBATTO_LEGENDRE)).finalize_all(axis_name='parts')
   assert arrays['elements'].shape[0] == num_partitions
+
+
+def test_hdf5_snapshot_container_round_trip(tmp_path):
+  """`write_snapshots` produces HDF5 (reference niles/datagen/datagen.py:
+  127-165: datasets 't', 'u', 'p' at the root) without h5py, through the HDF5
+  C library; files read back bit for bit, and the superblock signature is the
+  one every HDF5 reader checks."""
+  import numpy as np
+  from swirl_fem_amd.niles.datagen import datagen, h5lite
+  assert h5lite.available()
+  rng = np.random.default_rng(0)
+  data = {'t': np.linspace(0.0, 1e-3, 6), 'u': rng.standard_normal((6, 50, 2)),
+          'p': rng.standard_normal((6, 17)).astype(np.float32)}
+  path = datagen.write_snapshots(str(tmp_path / 'cycle_0_5'), data)
+  assert path.endswith('.hdf5')
+  with open(path, 'rb') as f:
+    assert f.read(8) == b'\x89HDF\r\n\x1a\n'
+  back = datagen.read_snapshots(path)
+  assert sorted(back) == ['p', 't', 'u']
+  for k, v in data.items():
+    assert back[k].dtype == v.dtype and back[k].shape == v.shape
+    np.testing.assert_array_equal(back[k], v)
+  # integer / empty / scalar-shaped datasets, and overwriting a file
+  more = {'ids': np.arange(5, dtype=np.int32), 'empty': np.zeros((0, 3)),
+          'flag': np.array([True, False])}
+  h5lite.write(path, more)
+  back = h5lite.read(path)
+  assert back['ids'].tolist() == [0, 1, 2, 3, 4] and back['empty'].shape == (0, 3)
+  assert back['flag'].tolist() == [1, 0] and 'u' not in back
+  npz = datagen.write_snapshots(str(tmp_path / 'c'), data, format='npz')
+  assert npz.endswith('.npz')
+  np.testing.assert_array_equal(datagen.read_snapshots(npz)['u'], data['u'])
+  with pytest.raises(ValueError):
+    datagen.write_snapshots(str(tmp_path / 'd'), data, format='netcdf')
