@@ -14,6 +14,16 @@ the primitive it is adjoint to:
 Callers (`Mesh`, `FiniteElementSpace`, `StokesVelocity`, `basis.interp`)
 switch to these when an operand requires grad; nothing changes for plain
 tensors.  Solves are differentiated by `linalg.cg.symmetric_solve`.
+
+The fused operator kernels are linear maps too and carry their transposes the
+same way, so a differentiated Navier-Stokes step keeps the fused path for its
+linear operators (only the quadratic convection term drops to the generic
+q-function path):
+
+    helmholtz apply  y = M S L G u   ->  u_bar = S L G (M y_bar)   (L symmetric)
+    helmholtz local  y = L u         ->  u_bar = L y_bar
+    stokes div       y = D u         ->  u_bar = D^T y_bar  (unmasked grad_t)
+    stokes grad_t    y = M D^T p     ->  p_bar = D (M y_bar)
 """
 
 from __future__ import annotations
@@ -146,6 +156,82 @@ class _BasisEvalT(torch.autograd.Function):
     g0 = val * wdet[:, :, None] if has0 else None
     g1 = grad * wdet[:, :, None, None] if has1 else None
     return (g0, g1) + (None,) * 9
+
+
+class _HelmholtzApply(torch.autograd.Function):
+  """`op.apply(u, l0, l1)` of a fused `HelmholtzOperator` with Dirichlet mask;
+  `op_free` is the same operator without mask, `keep` (N,) is 1 off the mask."""
+
+  @staticmethod
+  def forward(ctx, u, op, op_free, keep, l0, l1):
+    ctx.op_free, ctx.keep, ctx.l0, ctx.l1 = op_free, keep, l0, l1
+    return op.apply(u, l0, l1)
+
+  @staticmethod
+  def backward(ctx, g):
+    g = g.contiguous()
+    if ctx.keep is not None:
+      g = g * (ctx.keep if g.dim() == 1 else ctx.keep[:, None])
+    return ctx.op_free.apply(g, ctx.l0, ctx.l1), None, None, None, None, None
+
+
+class _HelmholtzLocal(torch.autograd.Function):
+  """`op.apply_local(u_local, l0, l1)`: symmetric per element."""
+
+  @staticmethod
+  def forward(ctx, u_local, op, l0, l1):
+    ctx.op, ctx.l0, ctx.l1 = op, l0, l1
+    return op.apply_local(u_local, l0, l1)
+
+  @staticmethod
+  def backward(ctx, g):
+    return ctx.op.apply_local(g.contiguous(), ctx.l0, ctx.l1), None, None, None
+
+
+class _StokesDiv(torch.autograd.Function):
+  """`op.div(u)`; `op_free` = the same `StokesDivGrad` without Dirichlet mask
+  (its `grad_t` is the exact transpose of `div`)."""
+
+  @staticmethod
+  def forward(ctx, u, op, op_free):
+    ctx.op_free = op_free
+    return op.div(u)
+
+  @staticmethod
+  def backward(ctx, g):
+    return ctx.op_free.grad_t(g.contiguous()), None, None
+
+
+class _StokesGradT(torch.autograd.Function):
+  """`op.grad_t(p)` = M D^T p; the transpose is D (M .)."""
+
+  @staticmethod
+  def forward(ctx, p, op, keep):
+    ctx.op, ctx.keep = op, keep
+    return op.grad_t(p)
+
+  @staticmethod
+  def backward(ctx, g):
+    g = g.contiguous()
+    if ctx.keep is not None:
+      g = g * ctx.keep[:, None]
+    return ctx.op.div(g), None, None
+
+
+def helmholtz_apply(op, op_free, keep, u, l0, l1):
+  return _HelmholtzApply.apply(u, op, op_free, keep, float(l0), float(l1))
+
+
+def helmholtz_local(op, u_local, l0, l1):
+  return _HelmholtzLocal.apply(u_local, op, float(l0), float(l1))
+
+
+def stokes_div(op, op_free, u):
+  return _StokesDiv.apply(u, op, op_free)
+
+
+def stokes_grad_t(op, keep, p):
+  return _StokesGradT.apply(p, op, keep)
 
 
 # ------------------------------------------------------------- entry points

@@ -324,8 +324,10 @@ class StokesVelocity:
 
   def A_local(self, u_local):
     """Apply the velocity stiffness operator locally."""
-    op = None if autodiff.needs_grad(u_local) else self._fused()
+    op = self._fused()
     if op is not None:
+      if autodiff.needs_grad(u_local):
+        return autodiff.helmholtz_local(op, u_local, 0.0, 1.0)
       return op.apply_local(u_local, 0.0, 1.0)
 
     def a(u, v):
@@ -337,8 +339,10 @@ class StokesVelocity:
 
   def B_local(self, u_local):
     """Apply the velocity mass operator locally."""
-    op = None if autodiff.needs_grad(u_local) else self._fused()
+    op = self._fused()
     if op is not None:
+      if autodiff.needs_grad(u_local):
+        return autodiff.helmholtz_local(op, u_local, 1.0, 0.0)
       return op.apply_local(u_local, 1.0, 0.0)
 
     def l(u, v):
@@ -455,8 +459,10 @@ class StokesSEM:
 
   def A(self, u):
     """Apply the stiffness operator to a velocity field."""
-    op = None if autodiff.needs_grad(u) else self._masked_operator()
+    op = self._masked_operator()
     if op is not None:
+      if autodiff.needs_grad(u):
+        return self._fused_apply_diff(op, u, 0.0, 1.0)
       return op.apply(u, 0.0, 1.0)
     return self.velocity.interior_mask * self.velocity.scatter(
         self.velocity.A_local(self.velocity.gather(u)))
@@ -464,10 +470,19 @@ class StokesSEM:
   def H(self, u, mass_coeff: float, mu: float):
     """Helmholtz operator `mass_coeff * B + mu * A` (reference :431) in one
     fused kernel; equals `mass_coeff * self.B(u) + mu * self.A(u)`."""
-    op = None if autodiff.needs_grad(u) else self._masked_operator()
+    op = self._masked_operator()
     if op is not None:
+      if autodiff.needs_grad(u):
+        return self._fused_apply_diff(op, u, mass_coeff, mu)
       return op.apply(u, mass_coeff, mu)
     return mass_coeff * self.B(u) + mu * self.A(u)
+
+  def _fused_apply_diff(self, op, u, l0, l1):
+    """Fused apply that autograd can differentiate (`autodiff._HelmholtzApply`:
+    the cotangent goes through the unmasked twin of the operator)."""
+    return autodiff.helmholtz_apply(op, self.velocity._fused(),
+                                    self.velocity.interior_mask[:, 0], u, l0,
+                                    l1)
 
   def C(self, u):
     """Apply the convection operator to a velocity field."""
@@ -506,15 +521,27 @@ class StokesSEM:
 
   def D(self, u):
     """Velocity divergence matrix."""
-    op = None if autodiff.needs_grad(u) else self._divgrad()
+    op = self._divgrad()
     if op is not None:
+      if autodiff.needs_grad(u):
+        return autodiff.stokes_div(op, self._divgrad_free(), u)
       return op.div(u)
     return self.pressure.scatter(self.D_local(self.velocity.gather(u)))
 
+  def _divgrad_free(self):
+    """`_divgrad()` without the Dirichlet mask: its `grad_t` is the exact
+    transpose of `div` (the cotangent rule of the fused divergence)."""
+    if 'divgrad_free' not in self._cache:
+      self._cache['divgrad_free'] = operators.StokesDivGrad.create(
+          self.velocity.vspace, self.pressure.pspace, None)
+    return self._cache['divgrad_free']
+
   def Dt(self, p):
     """Apply the pressure gradient operator."""
-    op = None if autodiff.needs_grad(p) else self._divgrad()
+    op = self._divgrad()
     if op is not None:
+      if autodiff.needs_grad(p):
+        return autodiff.stokes_grad_t(op, self.velocity.interior_mask[:, 0], p)
       return op.grad_t(p)
     return self.velocity.interior_mask * self.velocity.scatter(
         self.Dt_local(self.pressure.gather(p)))

@@ -150,3 +150,47 @@ def test_gather_scatter_exchange_rules():
   with torch.no_grad():
     assert torch.allclose(g, mesh.exchange(v), rtol=0, atol=1e-13)
   assert not autodiff.needs_grad(u.detach())
+
+
+def test_linear_operators_stay_on_the_fused_kernels_under_autograd(monkeypatch):
+  """A, B_local-based pieces, H, D, D^T and E differentiate through the FUSED
+  kernels (`core/autodiff.py`: each carries its transpose); only the quadratic
+  convection term needs the generic q-function path.  The generic path is
+  switched off here, so a cotangent that still arrives came from the fused
+  rules; it must equal the one of the generic path."""
+  sem = _sem(ndim=3, n=2, order=3)
+  Nv = sem.velocity.mesh.num_nodes
+  Np = sem.pressure.pspace.mesh.num_nodes
+  ops = {'A': (sem.A, (Nv, 3)), 'H': (lambda u: sem.H(u, 2.0, 0.3), (Nv, 3)),
+         'D': (sem.D, (Nv, 3)), 'Dt': (sem.Dt, (Np,)),
+         'E': (lambda p: sem.E(p, dt=1e-2, time_order=2), (Np,)),
+         'A_local': (sem.velocity.A_local, (sem.velocity.mesh.num_elements,
+                                            64, 3))}
+  generic = {}
+  from swirl_fem_amd.core import autodiff
+  real_needs_grad = autodiff.needs_grad
+  for k, (name, (op, shape)) in enumerate(ops.items()):
+    x = _rand(shape, 300 + k, grad=True)
+    w = _rand(tuple(op(x.detach()).shape), 400 + k)
+    generic[name] = (x, w)
+  fused_grads = {}
+  for name, (op, _) in ops.items():
+    x, w = generic[name]
+    (fused_grads[name],) = torch.autograd.grad((op(x) * w).sum(), x)
+
+  def boom(*a, **k):
+    raise AssertionError('generic q-function path used')
+  for space in (sem.velocity.vspace, sem.pressure.pspace):
+    monkeypatch.setattr(type(space), 'local_covector', boom)
+  for name, (op, _) in ops.items():
+    x, w = generic[name]
+    (g,) = torch.autograd.grad((op(x) * w).sum(), x)   # no generic call
+    # (same kernels both times; the atomics may sum in another order)
+    assert float((g - fused_grads[name]).abs().max()) <= 1e-12 * float(
+        g.abs().max())
+    # transpose check: <w, op(v)> == <g, v> for a linear op
+    v = _rand(tuple(x.shape), 500)
+    with torch.no_grad():
+      lhs = float((op(v) * w).sum())
+    rhs = float((g * v).sum())
+    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), 1.0), name
