@@ -411,6 +411,12 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *                      late; phase 6 = close the open iteration now (before
  *                      the host reads [0], [7] or [8]);
  *                      phases 1 and 2 clear `partials` when it is given
+ *                      gamma_new is scalars[2] PLUS the SFEM_CG_RR_SLOTS partial
+ *                      sums scalars[16..80): sfem_cg_update_r with fuse_rr = 2
+ *                      spreads its per-workgroup r.r sums over them (one
+ *                      address would serialise 32 k atomics); every consumer
+ *                      (update_p, update_xp, the closing phases) adds them up,
+ *                      the closing phases clear them
  * sfem_cg_update_xr:   x += alpha p; r -= alpha Ap;  (cg.py:80-81)
  *                      fuse_rr != 0 also accumulates gamma_new += r.r (M = I)
  * sfem_cg_update_p:    p = z + beta p                (cg.py:84-85)
@@ -418,7 +424,9 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *                      8 instead of 9 vector passes (bitwise the same result):
  *                      r -= alpha Ap (+ gamma_new += r.r), then, once beta is
  *                      known,  x += alpha p;  p = z + beta p                   */
-#define SFEM_CG_NSCALARS 16
+#define SFEM_CG_NSCALARS_NAMED 16 /* [0..16): the named scalars above      */
+#define SFEM_CG_RR_SLOTS 64       /* [16..80): partial sums of gamma_new     */
+#define SFEM_CG_NSCALARS (SFEM_CG_NSCALARS_NAMED + SFEM_CG_RR_SLOTS)
 #define SFEM_CG_STATUS_RUNNING 0.0
 #define SFEM_CG_STATUS_CONVERGED 1.0
 #define SFEM_CG_STATUS_MAXITER 2.0

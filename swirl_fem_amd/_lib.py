@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get('SFEM_LIB') or os.path.join(_HERE, 'libsfem_hip.so')
 ABI_VERSION = 3
 
 SFEM_F32, SFEM_F64 = 0, 1
-SFEM_CG_NSCALARS = 16
+SFEM_CG_NSCALARS_NAMED = 16
+SFEM_CG_NSCALARS = 80      # 16 named scalars + 64 partial sums of gamma_new
 CG_STATUS = {0: 'running', 1: 'converged', 2: 'maxiter', 3: 'breakdown_pAp',
              4: 'breakdown_gamma'}
 SFEM_DOT_SLOTS = 1024

@@ -400,6 +400,18 @@ dot_indexed_kernel(const T* __restrict__ a, const T* __restrict__ b,
   if (threadIdx.x == 0 && total != 0.0) unsafeAtomicAdd(result, scale * total);
 }
 
+// gamma_new = scalars[2] + the SFEM_CG_RR_SLOTS partial sums behind the named
+// scalars.  `cg_update_r` with fuse_rr = 2 spreads its per-workgroup r.r sums
+// over those slots: one address would serialise the atomics of all workgroups
+// (the reason the fused kernels were held to 16 workgroups per CU), 64 let the
+// update stream with 128 per CU.  Every wave sums the slots for itself.
+__device__ __forceinline__ double cg_gamma_new(const double* scalars) {
+  double v = scalars[SFEM_CG_NSCALARS_NAMED + (threadIdx.x & 63)];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return scalars[2] + v;
+}
+
 template <typename T, bool FUSE_RR>
 __global__ void __launch_bounds__(512)
 cg_update_xr_kernel(T* __restrict__ x, T* __restrict__ r,
@@ -451,7 +463,7 @@ cg_update_p_kernel(T* __restrict__ p, const T* __restrict__ z, int64_t count,
   if (scalars[7] != 0.0) return;
   using V = typename Vec16<T>::type;
   constexpr int VN = Vec16<T>::N;
-  const T beta = (T)(scalars[2] / scalars[0]);
+  const T beta = (T)(cg_gamma_new(scalars) / scalars[0]);
   const int64_t nvec = count / VN;
   V* pv = reinterpret_cast<V*>(p);
   const V* zv = reinterpret_cast<const V*>(z);
@@ -477,7 +489,7 @@ cg_update_p_kernel(T* __restrict__ p, const T* __restrict__ z, int64_t count,
 // p update, where p is in registers anyway.
 //   update_r : r -= alpha Ap (+ gamma_new += r.r)        reads r, Ap; writes r
 //   update_xp: x += alpha p;  p = z + beta p             reads x, p, z; writes x, p
-template <typename T, bool FUSE_RR, bool NT>
+template <typename T, bool FUSE_RR, bool NT, bool STRIPED = false>
 __global__ void __launch_bounds__(512)
 cg_update_r_kernel(T* __restrict__ r, const T* __restrict__ ap, int64_t count,
                    double* __restrict__ scalars) {
@@ -510,7 +522,10 @@ cg_update_r_kernel(T* __restrict__ r, const T* __restrict__ ap, int64_t count,
   }
   if (FUSE_RR) {
     const double total = block_sum(acc);
-    if (threadIdx.x == 0) unsafeAtomicAdd(&scalars[2], total);
+    if (threadIdx.x == 0)
+      unsafeAtomicAdd(STRIPED ? &scalars[SFEM_CG_NSCALARS_NAMED +
+                                         (blockIdx.x & (SFEM_CG_RR_SLOTS - 1))]
+                              : &scalars[2], total);
   }
 }
 
@@ -523,7 +538,7 @@ cg_update_xp_kernel(T* __restrict__ x, T* __restrict__ p,
   using V = typename Vec16<T>::type;
   constexpr int VN = Vec16<T>::N;
   const T alpha = (T)(scalars[0] / scalars[1]);
-  const T beta = (T)(scalars[2] / scalars[0]);
+  const T beta = (T)(cg_gamma_new(scalars) / scalars[0]);
   const int64_t nvec = count / VN;
   V* xv = reinterpret_cast<V*>(x);
   V* pv = reinterpret_cast<V*>(p);
@@ -553,12 +568,19 @@ cg_update_xp_kernel(T* __restrict__ x, T* __restrict__ p,
 }
 
 template <typename T>
-static void launch_update_r(bool fuse_rr, bool nt, int grid, hipStream_t stream,
+static void launch_update_r(int fuse_rr, bool nt, int grid, hipStream_t stream,
                             T* r, const T* ap, int64_t count, double* scalars) {
 #define SFEM_UPDATE_R(FUSE, NTV)                                             \
   hipLaunchKernelGGL((cg_update_r_kernel<T, FUSE, NTV>), dim3(grid),         \
                      dim3(512), 0, stream, r, ap, count, scalars)
-  if (fuse_rr) {
+  if (fuse_rr == 2) {
+    if (nt)
+      hipLaunchKernelGGL((cg_update_r_kernel<T, true, true, true>), dim3(grid),
+                         dim3(512), 0, stream, r, ap, count, scalars);
+    else
+      hipLaunchKernelGGL((cg_update_r_kernel<T, true, false, true>), dim3(grid),
+                         dim3(512), 0, stream, r, ap, count, scalars);
+  } else if (fuse_rr) {
     if (nt) SFEM_UPDATE_R(true, true);
     else SFEM_UPDATE_R(true, false);
   } else {
@@ -594,7 +616,11 @@ __device__ __forceinline__ bool cg_bad_pap(double v) {
 // closes an iteration: beta, gamma <- gamma_new, counter, stop test
 __device__ __forceinline__ void cg_close_iteration(double* scalars,
                                                    double maxiter) {
-  const double g = scalars[2];
+  double g = scalars[2];
+  for (int q = 0; q < SFEM_CG_RR_SLOTS; ++q) {     // striped r.r (fuse_rr = 2)
+    g += scalars[SFEM_CG_NSCALARS_NAMED + q];
+    scalars[SFEM_CG_NSCALARS_NAMED + q] = 0.0;
+  }
   scalars[4] = g / scalars[0];
   scalars[0] = g;
   scalars[8] += 1.0;
@@ -673,6 +699,8 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     scalars[2] = 0.0;
     scalars[8] = 0.0;
     scalars[9] = 0.0;
+    for (int q = 0; q < SFEM_CG_RR_SLOTS; ++q)
+      scalars[SFEM_CG_NSCALARS_NAMED + q] = 0.0;
     scalars[10] = SFEM_CG_STATUS_RUNNING;
     scalars[7] = 0.0;
     if (cg_bad_gamma(scalars[0])) {
@@ -1035,8 +1063,12 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
   SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_r: bad arguments");
   if (count == 0) return SFEM_OK;
   SFEM_REQUIRE(r && ap, "sfem_cg_update_r: null pointer");
+  SFEM_REQUIRE(fuse_rr >= 0 && fuse_rr <= 2, "sfem_cg_update_r: bad fuse_rr");
   DISPATCH_DTYPE(dtype, {
-    const int grid = reduce_grid(count, 512 * 2);
+    // fuse_rr = 2: the per-workgroup sums are spread over SFEM_CG_RR_SLOTS
+    // addresses, so the update can stream with 128 workgroups per CU
+    const int grid = fuse_rr == 2 ? stream_grid(count, 512 * 2)
+                                  : reduce_grid(count, 512 * 2);
     launch_update_r<T>(fuse_rr, streams_past_caches(count, sizeof(T)), grid,
                        as_stream(stream), (T*)r, (const T*)ap, count, scalars);
   });

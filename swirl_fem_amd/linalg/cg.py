@@ -135,6 +135,11 @@ class CGRunner:
     self.parts = s.partials if self.fused_dot else None
     _ops.cg_scalars(s.t, 2, maxiter, tol, atol, self.parts)
     self.fuse_rr = self.identity_m and dot_fn is None
+    # r.r spread over 64 slots (update_r then streams with 128 workgroups per
+    # CU) unless something needs the complete sum in the named slot right
+    # after the update: an all-reduce or the interface correction
+    if self.fuse_rr and reduce_fn is None and interface is None:
+      self.fuse_rr = 2
     self.issued = 0
     self._graph = None
 

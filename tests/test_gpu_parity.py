@@ -908,17 +908,19 @@ def test_cg_with_fused_operator_dot():
 def test_cg_update_groupings_agree(dtype):
   """9-pass (xr, p) and 8-pass (r, xp) groupings of the CG vector updates are
   the same arithmetic; odd lengths exercise the scalar tails."""
-  from swirl_fem_amd import _ops
+  from swirl_fem_amd import _lib, _ops
   g = torch.Generator(device=DEV).manual_seed(3)
   for n in (1, 7, 1000, 100003):
     v = [torch.randn(n, dtype=dtype, device=DEV, generator=g) for _ in range(4)]
-    s = torch.zeros(16, dtype=torch.float64, device=DEV)
+    s = torch.zeros(_lib.SFEM_CG_NSCALARS, dtype=torch.float64, device=DEV)
     s[0], s[1] = 2.5, 1.7                      # gamma, p.Ap -> alpha = gamma / pAp
-    for fuse in (True, False):
+    # fuse 1: r.r by atomics on the named slot; 2: spread over the 64 partial
+    # slots behind the named scalars (what the single-GPU solver uses)
+    for fuse in (1, 2, 0):
       x1, r1, p1, ap = (t.clone() for t in v)
       x2, r2, p2 = x1.clone(), r1.clone(), p1.clone()
       s1, s2 = s.clone(), s.clone()
-      _ops.cg_update_xr(x1, r1, p1, ap, s1, fuse)
+      _ops.cg_update_xr(x1, r1, p1, ap, s1, min(fuse, 1))
       _ops.cg_update_r(r2, ap, s2, fuse)
       if not fuse:                              # gamma_new from a separate dot
         s1[2] = s2[2] = float((r1.double() ** 2).sum())
@@ -931,8 +933,15 @@ def test_cg_update_groupings_agree(dtype):
       assert float((p1 - p2).abs().max()) <= 100 * tol * float(p1.abs().max())
       alpha = 2.5 / 1.7
       assert float((x1 - (v[0] + alpha * v[2])).abs().max()) < tol * 10
-      assert abs(float(s1[2]) - float((r1.double() ** 2).sum())) < 1e-9 * n
-      assert float(s1[2]) == float(s2[2]) or fuse   # atomics: order may differ
+      rr = float((r1.double() ** 2).sum())
+      assert abs(float(s1[2]) - rr) < 1e-9 * n
+      gamma_new = float(s2[2]) + float(s2[_lib.SFEM_CG_NSCALARS_NAMED:].sum())
+      assert abs(gamma_new - rr) < 1e-9 * n
+      assert (float(s2[2]) == 0.0) == (fuse == 2)
+      # closing the iteration folds the partial sums into gamma and clears them
+      _ops.cg_scalars(s2, 1, 10 ** 9, 0.0, 0.0)
+      assert abs(float(s2[0]) - rr) < 1e-9 * n
+      assert float(s2[_lib.SFEM_CG_NSCALARS_NAMED:].abs().max()) == 0.0
 
 
 def test_symmetric_solve_is_differentiable_in_b():
