@@ -7,6 +7,7 @@ number is produced by `libsfem_hip.so`.  All tensors must live on the GPU.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -447,6 +448,10 @@ def helmholtz_cluster_limits(P, dtype):
 def helmholtz_kernel_name(real, P, ndim, scalar, geo_mode, part, mass):
   """Mirror of `launch_helmholtz`'s choice (csrc/sfem_helmholtz.h)."""
   b = lambda v: 'true' if v else 'false'
+  if (real == 'float' and P == 12 and ndim == 3 and scalar and
+      geo_mode in (1, 3) and part.get('cluster') is None and
+      not part.get('colored') and os.environ.get('SFEM_MFMA', '0') == '1'):
+    return 'sfem::helmholtz_mfma_p12_kernel<%d, %s>' % (geo_mode, b(mass))
   if part.get('cluster') is not None:
     return 'sfem::helmholtz_cluster_kernel<%s, %d, %s, %d, %s>' % (
         real, P, b(scalar), geo_mode, b(mass))

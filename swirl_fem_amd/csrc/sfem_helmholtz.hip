@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "sfem_helmholtz_cluster.h"
+#include "sfem_helmholtz_mfma.h"
 
 namespace sfem {
 
@@ -149,6 +150,15 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
     ClusterParams<T> cl{c.cluster_elems, c.cluster_offsets, c.cluster_nodes,
                         c.num_clusters};
     return dispatch_helmholtz_cluster<T>(prm, cl, c.P, stream);
+  }
+  if constexpr (sizeof(T) == 4) {
+    // p = 11 fp32: the contractions on the matrix cores, opt-in (SFEM_MFMA=1):
+    // measured 1.25 vs 1.0 ms for the vector-ALU kernel at 48^3 elements
+    // (profiles/r02_mfma_notes.md), so not the default
+    const char* v = getenv("SFEM_MFMA");
+    const bool mfma_on = v && v[0] == '1';
+    if (mfma_on && helmholtz_mfma_applies(prm, c.P, c.ndim, c.gs))
+      return launch_helmholtz_mfma_p12(prm, stream);
   }
   if (c.ndim == 3) return dispatch_helmholtz<T, 3>(prm, c.P, c.gs, stream);
   if (c.ndim == 2) return dispatch_helmholtz<T, 2>(prm, c.P, c.gs, stream);

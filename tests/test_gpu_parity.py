@@ -513,6 +513,57 @@ def test_fused_helmholtz_fp32_and_vector(ndim, n, P):
       assert relerr(got, ofes.stiffness_local(ul)) < tol
 
 
+@pytest.mark.parametrize('mode', ['structured', 'sheared', 'jittered',
+                                  'mixed'])
+def test_matrix_core_helmholtz_p11_fp32(mode, monkeypatch):
+  """`helmholtz_mfma_p12_kernel` (p = 11, fp32: the 12 x 12 contractions as
+  v_mfma_f32_16x16x4_f32 tiles) vs the oracle and vs the vector-ALU kernel of
+  the same operator: affine and multilinear elements, mass on / off, pure
+  mass, Dirichlet mask, fused u . A u, element lists (a mesh that also has
+  curved elements keeps those on the vector-ALU kernel)."""
+  from swirl_fem_amd import _lib
+  P, n = 12, 2 if mode != 'mixed' else 3
+  rng = np.random.default_rng(71)
+  pm = unit_cube_mesh(n, ndim=3)
+  x = pm.node_coords.copy()
+  if mode == 'sheared':
+    x = x @ (np.eye(3) + 0.25 * rng.uniform(-1, 1, (3, 3))).T + 0.2
+  if mode in ('jittered', 'mixed'):
+    x = x + 0.08 / n * rng.uniform(-1, 1, x.shape)
+  rp = refine_premesh(pm.replace(node_coords=x), Nodes1D.create(P, NT['gll']))
+  if mode == 'mixed':           # bend the nodes of the first layer of elements
+    xc = rp.node_coords.copy()
+    inside = (xc[:, 0] > 1e-9) & (xc[:, 0] < 1 / 3 - 1e-9)   # first layer only
+    xc[:, 2] += 0.02 * np.sin(3 * np.pi * xc[:, 0]) * inside * (
+        xc[:, 2] * (1 - xc[:, 2]))
+    rp = rp.replace(node_coords=xc)
+  mesh, fes, ofes = spaces(rp, P, P, 'gll', torch.float32)
+  bmask = mesh.physical_masks['boundary'].cpu().numpy()
+  op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
+  if mode in ('structured', 'sheared'):
+    assert op.num_affine == mesh.num_elements
+  if mode == 'mixed':
+    assert op.num_curved > 0 and op.num_multilinear + op.num_affine > 0, (
+        op.num_curved, op.num_multilinear, op.num_affine)
+  monkeypatch.setenv('SFEM_MFMA', '1')
+  assert 'helmholtz_mfma_p12_kernel' in op.kernel_name(0.5, 1.0)
+  u = rng.standard_normal(mesh.num_nodes)
+  ud = dev(u, torch.float32)
+  for l0, l1 in ((0.0, 1.0), (0.7, 1.2), (1.0, 0.0)):
+    ref = _helmholtz_ref(ofes, u, l0, l1, bmask)
+    monkeypatch.setenv('SFEM_MFMA', '1')
+    parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64, device=DEV)
+    got = op.apply(ud, l0, l1, dot_out=parts)
+    assert relerr(got, ref) < 2e-5, (mode, l0, l1)
+    want, scale = float((u * ref).sum()), float(np.abs(u * ref).sum())
+    assert abs(float(parts.sum()) - want) <= 3e-4 * scale
+    monkeypatch.setenv('SFEM_MFMA', '0')
+    assert 'helmholtz_kernel<float, 12' in op.kernel_name(l0, l1)
+    valu = op.apply(ud, l0, l1)
+    assert relerr(valu, ref) < 2e-5
+    assert relerr(got, valu.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize('ndim,n,P', [(2, 4, 5), (3, 3, 4), (3, 3, 8)])
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
 def test_fused_helmholtz_geometry_kinds(ndim, n, P, dtype):
