@@ -44,7 +44,9 @@
 // matrix pipes 20 % busy -- but 1.25 ms against 1.0 ms for the vector-ALU kernel:
 // the results of a product stage reach the next stage only through LDS (406 vs
 // 288 LDS instructions per element) and six workgroup barriers per element
-// leave the waves waiting (issue stalls 3x).  Opt-in with SFEM_MFMA=1.
+// leave the waves waiting (issue stalls 3x).  With the LDS accesses of each
+// stage batched (all loads, then all stores): 1.19 ms affine, 1.31 vs 1.34 ms
+// on multilinear elements (128-VGPR budget there).  Opt-in with SFEM_MFMA=1.
 //
 // Everything outside the MFMAs uses ONE thread-to-point mapping: wave w, lane l
 // works on the points (a, c) with a = 3w .. 3w+2 and c = l + 64 r2 (r2 < 3,
@@ -91,13 +93,19 @@ template <int AX, int T0, int T1, int OFF>
 __device__ __forceinline__ void mfma_tiles(const float (&aM)[3],
                                            const float* src, int q, int m,
                                            mfma_f4 (&res)[7]) {
+  // all B operands first (one LDS round trip), then the MFMA chains
+  float b[T1 - T0][3];
+#pragma unroll
+  for (int t = T0; t < T1; ++t)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b[t - T0][s] = src[mfma_b_addr<AX>(q, m, s, t)];
 #pragma unroll
   for (int t = T0; t < T1; ++t) {
     mfma_f4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(
-          aM[s], src[mfma_b_addr<AX>(q, m, s, t)], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(aM[s], b[t - T0][s], c, 0, 0,
+                                               0);
     res[OFF + t - T0] = c;
   }
 }
@@ -142,13 +150,15 @@ __device__ __forceinline__ void mfma_stage(const float (&aM)[3], int wave,
 }
 
 template <int GM, bool MASS>
-__global__ void __launch_bounds__(256, SFEM_MFMA_MINW)
+__global__ void __launch_bounds__(256, (GM == GEO_AFFINE ? SFEM_MFMA_MINW : 4))
 helmholtz_mfma_p12_kernel(MfmaConsts<12> cst, HelmholtzParams<float> prm) {
   constexpr int P = 12, PP = P * P, N = P * P * P;
   constexpr int KS = P / 4;            // 3 k steps
   constexpr int R2 = 3;                // columns per lane: c = lane + 64 r2
   constexpr int AW = 3;                // slices per wave: a = 3 wave + ai
-  __shared__ float lds[3 * N];
+  // 3 arrays + a 64-float sink: lanes without a point (c >= 144 in the r2 = 2
+  // steps) read and write there, so the point loops carry no branches
+  __shared__ float lds[3 * N + 64];
   float* A0 = lds;
   float* A1 = lds + N;
   float* A2 = lds + 2 * N;
@@ -176,6 +186,15 @@ helmholtz_mfma_p12_kernel(MfmaConsts<12> cst, HelmholtzParams<float> prm) {
 
   // ---- gather in the point mapping: slot(ai, r2) = (3 wave + ai) 144 + c
   const int a0 = AW * wave;
+  // LDS position of point (ai, r2) relative to A0 / A1 / A2 (A2's view of the
+  // sink is shifted by -2N, A1's by -N, so all three land inside it)
+  int col[R2];
+  bool has[R2];
+#pragma unroll
+  for (int r2 = 0; r2 < R2; ++r2) {
+    has[r2] = lane + 64 * r2 < PP;
+    col[r2] = has[r2] ? lane + 64 * r2 : -1;
+  }
   uint32_t enc[AW][R2];
   float ua[AW][R2], wa[AW], xa[AW];
   {
@@ -277,36 +296,55 @@ helmholtz_mfma_p12_kernel(MfmaConsts<12> cst, HelmholtzParams<float> prm) {
   if (has_stiff) {
     // ---- forward products: the gradients along the three axes
     mfma_stage(aD, wave, q, m, A0, A0, A0, A0, A1, A2);
-    // ---- point-wise: (w0, w1, w2) = w detJ J^-1 J^-T (g0, g1, g2), in place
+    // ---- point-wise: (w0, w1, w2) = w detJ J^-1 J^-T (g0, g1, g2), in place.
+    // All loads first, all stores last: one LDS round trip for the stage
+    // instead of one per point (the compiler cannot hoist a load over an
+    // earlier store into the same array).
+    float h[AW][R2][3];
+    int slot[AW][R2];
 #pragma unroll
     for (int ai = 0; ai < AW; ++ai)
 #pragma unroll
       for (int r2 = 0; r2 < R2; ++r2) {
-        const int c = lane + 64 * r2;
-        if (c < PP) {
-          const int slot = (a0 + ai) * PP + c;
-          const float h0 = A0[slot], h1 = A1[slot], h2 = A2[slot];
-          const float wq = wa[ai] * wij[r2];
-          float w0, w1, w2;
-          if (GM == GEO_AFFINE) {
-            w0 = wq * (cg[0] * h0 + cg[1] * h1 + cg[2] * h2);
-            w1 = wq * (cg[1] * h0 + cg[3] * h1 + cg[4] * h2);
-            w2 = wq * (cg[2] * h0 + cg[4] * h1 + cg[5] * h2);
-          } else {
-            // G g = (w / det) C (C^T g), C = rows of cofactors
-            float c0[3], c1[3], c2[3];
-            const float det = jacobian(xa[ai], xi[r2], xj[r2], c0, c1, c2);
-            const float sc = fast_div(wq, det);
-            float y[3];
+        // idle lanes: the sink behind the third array (index 3N - kN + lane)
+        slot[ai][r2] = has[r2] ? (a0 + ai) * PP + col[r2] : 3 * N + lane;
+        h[ai][r2][0] = A0[slot[ai][r2]];
+        h[ai][r2][1] = A0[slot[ai][r2] + (has[r2] ? N : 0)];
+        h[ai][r2][2] = A0[slot[ai][r2] + (has[r2] ? 2 * N : 0)];
+      }
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-              y[k] = sc * (c0[k] * h0 + c1[k] * h1 + c2[k] * h2);
-            w0 = c0[0] * y[0] + c0[1] * y[1] + c0[2] * y[2];
-            w1 = c1[0] * y[0] + c1[1] * y[1] + c1[2] * y[2];
-            w2 = c2[0] * y[0] + c2[1] * y[1] + c2[2] * y[2];
-          }
-          A0[slot] = w0; A1[slot] = w1; A2[slot] = w2;
+    for (int ai = 0; ai < AW; ++ai)
+#pragma unroll
+      for (int r2 = 0; r2 < R2; ++r2) {
+        const float h0 = h[ai][r2][0], h1 = h[ai][r2][1], h2 = h[ai][r2][2];
+        const float wq = wa[ai] * wij[r2];
+        float w0, w1, w2;
+        if (GM == GEO_AFFINE) {
+          w0 = wq * (cg[0] * h0 + cg[1] * h1 + cg[2] * h2);
+          w1 = wq * (cg[1] * h0 + cg[3] * h1 + cg[4] * h2);
+          w2 = wq * (cg[2] * h0 + cg[4] * h1 + cg[5] * h2);
+        } else {
+          // G g = (w / det) C (C^T g), C = rows of cofactors
+          float c0[3], c1[3], c2[3];
+          const float det = jacobian(xa[ai], xi[r2], xj[r2], c0, c1, c2);
+          const float sc = fast_div(wq, det);
+          float y[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            y[k] = sc * (c0[k] * h0 + c1[k] * h1 + c2[k] * h2);
+          w0 = c0[0] * y[0] + c0[1] * y[1] + c0[2] * y[2];
+          w1 = c1[0] * y[0] + c1[1] * y[1] + c1[2] * y[2];
+          w2 = c2[0] * y[0] + c2[1] * y[1] + c2[2] * y[2];
         }
+        h[ai][r2][0] = w0; h[ai][r2][1] = w1; h[ai][r2][2] = w2;
+      }
+#pragma unroll
+    for (int ai = 0; ai < AW; ++ai)
+#pragma unroll
+      for (int r2 = 0; r2 < R2; ++r2) {
+        A0[slot[ai][r2]] = h[ai][r2][0];
+        A0[slot[ai][r2] + (has[r2] ? N : 0)] = h[ai][r2][1];
+        A0[slot[ai][r2] + (has[r2] ? 2 * N : 0)] = h[ai][r2][2];
       }
     __syncthreads();
     // ---- transposed products, back at their natural positions
@@ -315,17 +353,26 @@ helmholtz_mfma_p12_kernel(MfmaConsts<12> cst, HelmholtzParams<float> prm) {
 
   // ---- sum, mass term, direct-stiffness summation (flags as helmholtz_kernel)
   double udot = 0.0;
+  float vsum[AW][R2];
 #pragma unroll
   for (int ai = 0; ai < AW; ++ai)
 #pragma unroll
     for (int r2 = 0; r2 < R2; ++r2) {
-      const int c = lane + 64 * r2;
+      vsum[ai][r2] = 0.f;
+      if (has_stiff) {
+        const int sl = has[r2] ? (a0 + ai) * PP + col[r2] : 3 * N + lane;
+        vsum[ai][r2] = A0[sl] + A0[sl + (has[r2] ? N : 0)] +
+                       A0[sl + (has[r2] ? 2 * N : 0)];
+      }
+    }
+#pragma unroll
+  for (int ai = 0; ai < AW; ++ai)
+#pragma unroll
+    for (int r2 = 0; r2 < R2; ++r2) {
       const uint32_t ea = enc[ai][r2];
       const uint32_t id = ea & SFEM_IDX_MASK;
-      if (c < PP && id != SFEM_IDX_PAD) {
-        const int slot = (a0 + ai) * PP + c;
-        float v = 0.f;
-        if (has_stiff) v = prm.lambda1 * (A0[slot] + A1[slot] + A2[slot]);
+      if (has[r2] && id != SFEM_IDX_PAD) {
+        float v = prm.lambda1 * vsum[ai][r2];
         if (MASS) {
           float W;
           if (GM == GEO_AFFINE) {
