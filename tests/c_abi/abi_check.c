@@ -34,6 +34,21 @@ static void* to_device(const void* src, size_t bytes) {
 
 int main(void) {
   CHECK(sfem_abi_version() == SFEM_ABI_VERSION, "ABI version");
+  {
+    /* limits of the cluster-assembly kernels: compiled for P = 4..8 */
+    int size = 0, kmax = 0;
+    CHECK(sfem_helmholtz_cluster_limits(8, SFEM_F64, &size, &kmax) == SFEM_OK &&
+              size == 8 && kmax >= 1647,
+          "cluster limits P=8 fp64 (a 2x2x2 cluster has 1647 table nodes)");
+    CHECK(sfem_helmholtz_cluster_limits(4, SFEM_F32, &size, &kmax) == SFEM_OK &&
+              size == 8 && kmax >= 8 * 56,
+          "cluster limits P=4 fp32");
+    CHECK(sfem_helmholtz_cluster_limits(9, SFEM_F64, &size, &kmax) ==
+              SFEM_EUNSUPPORTED && strlen(sfem_last_error()) > 0,
+          "cluster limits outside the compiled range");
+    CHECK(SFEM_CG_NSCALARS == SFEM_CG_NSCALARS_NAMED + SFEM_CG_RR_SLOTS,
+          "CG scalar block layout");
+  }
 
   /* --- gather / scatter-add with the -1 sentinel (gather_scatter.py:121-133) */
   {
