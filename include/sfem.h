@@ -410,6 +410,8 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *                      the done flag is then raised one (harmless) apply
  *                      late; phase 6 = close the open iteration now (before
  *                      the host reads [0], [7] or [8]);
+ *                      phase 7 = fold the striped r.r (below) into [2] now,
+ *                      before the caller corrects or all-reduces it;
  *                      phases 1 and 2 clear `partials` when it is given
  *                      gamma_new is scalars[2] PLUS the SFEM_CG_RR_SLOTS partial
  *                      sums scalars[16..80): sfem_cg_update_r with fuse_rr = 2

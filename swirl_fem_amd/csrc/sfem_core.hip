@@ -651,6 +651,19 @@ __global__ void __launch_bounds__(256)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
                  double atol, double* partials) {
   const int tid = threadIdx.x;
+  if (phase == 7) {
+    // fold the striped r.r into the named slot NOW: the caller is about to
+    // correct / all-reduce gamma_new (partitioned solves)
+    if (tid == 0 && scalars[7] == 0.0) {
+      double g = scalars[2];
+      for (int q = 0; q < SFEM_CG_RR_SLOTS; ++q) {
+        g += scalars[SFEM_CG_NSCALARS_NAMED + q];
+        scalars[SFEM_CG_NSCALARS_NAMED + q] = 0.0;
+      }
+      scalars[2] = g;
+    }
+    return;
+  }
   if (phase == 5 || phase == 6) {
     // Deferred bookkeeping: phase 5 sits between the apply and the updates
     // of iteration k+1 and first closes iteration k (what phase 1 does), so
@@ -1099,8 +1112,8 @@ int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
 
 int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
                     double atol, double* partials, sfem_stream_t stream) {
-  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 6 &&
-                   (phase < 3 || phase == 6 || partials),
+  SFEM_REQUIRE(scalars && phase >= 0 && phase <= 7 &&
+                   (phase < 3 || phase >= 6 || partials),
                "sfem_cg_scalars: bad arguments");
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
                      as_stream(stream), scalars, phase, maxiter, tol, atol,

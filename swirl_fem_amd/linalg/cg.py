@@ -135,11 +135,14 @@ class CGRunner:
     self.parts = s.partials if self.fused_dot else None
     _ops.cg_scalars(s.t, 2, maxiter, tol, atol, self.parts)
     self.fuse_rr = self.identity_m and dot_fn is None
-    # r.r spread over 64 slots (update_r then streams with 128 workgroups per
-    # CU) unless something needs the complete sum in the named slot right
-    # after the update: an all-reduce or the interface correction
-    if self.fuse_rr and reduce_fn is None and interface is None:
+    # r.r spread over 64 slots: update_r then streams with 128 workgroups per
+    # CU.  When something needs the complete sum in the named slot right after
+    # the update (an all-reduce, the interface correction) one tiny scalar
+    # launch folds the slots first.
+    if self.fuse_rr:
       self.fuse_rr = 2
+    self.fold_rr = self.fuse_rr == 2 and (reduce_fn is not None or
+                                          interface is not None)
     self.issued = 0
     self._graph = None
 
@@ -186,6 +189,8 @@ class CGRunner:
                        self.fuse_rr)
     if self.fuse_rr:
       z = self.r
+      if self.fold_rr:
+        _ops.cg_scalars(s.t, 7, *args)
       if self.interface is not None:
         s.interface_correction(S.GAMMA_NEW, self.r, self.r, self.interface)
       if reduce_fn is not None:
