@@ -37,6 +37,9 @@
 #pragma once
 #include "sfem_common.h"
 
+#ifndef SFEM_DMAT_MEM
+#define SFEM_DMAT_MEM 1
+#endif
 #ifndef SFEM_PK_F32
 #define SFEM_PK_F32 1
 #endif
@@ -207,6 +210,52 @@ __device__ __forceinline__ void line_apply(const DMat<T, P>& dm,
 #pragma unroll
     for (int m = 0; m < PH; ++m)
       so += (TRANS ? dm.e[m * PC + r] : dm.o[r * PH + m]) * xo[m];
+    if (r < PH) {
+      y[r] = so + se;
+      y[P - 1 - r] = so - se;
+    } else {
+      y[r] = so;
+    }
+  }
+}
+
+// The same product with the matrix read from MEMORY (the kernarg segment, a
+// constant address space: scalar loads, scalar-cache hits) instead of from the
+// by-value copy.  For P >= 9 the 72-entry even/odd matrix plus weights do not
+// fit the 102 SGPRs next to everything else, and the compiler spills scalars
+// into VGPR lanes: 250 v_readlane / v_writelane per wave at P = 12, 18 % of the
+// vector instructions of a kernel that is bound by them.  Reloading the entries
+// per product keeps them in SGPRs only while they are used.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SFEM_CONSTANT_AS __attribute__((address_space(4)))
+#else
+#define SFEM_CONSTANT_AS
+#endif
+template <typename T, int P, bool TRANS>
+__device__ __forceinline__ void line_apply_mem(
+    const SFEM_CONSTANT_AS DMat<T, P>* km, const T (&x)[P], T (&y)[P]) {
+  constexpr int PH = P / 2, PC = P - P / 2;
+  // a fresh pointer per product: loads are not merged across products (which
+  // would bring the register pressure back)
+  asm volatile("" : "+s"(km));
+  T xe[PC], xo[PH > 0 ? PH : 1];
+#pragma unroll
+  for (int m = 0; m < PH; ++m) {
+    xe[m] = x[m] + x[P - 1 - m];
+    xo[m] = x[m] - x[P - 1 - m];
+  }
+  if (PC > PH) xe[PH] = x[PH];
+#pragma unroll
+  for (int r = 0; r < PC; ++r) {
+    T se = T(0), so = T(0);
+    if (r < PH) {
+#pragma unroll
+      for (int m = 0; m < PC; ++m)
+        se += (TRANS ? km->o[m * PH + r] : km->e[r * PC + m]) * xe[m];
+    }
+#pragma unroll
+    for (int m = 0; m < PH; ++m)
+      so += (TRANS ? km->e[m * PC + r] : km->o[r * PH + m]) * xo[m];
     if (r < PH) {
       y[r] = so + se;
       y[P - 1 - r] = so - se;
@@ -845,6 +894,24 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
   T* s0 = lds + (lane_ok ? el : 0) * 2 * W;    // becomes the axis-1 result
   T* s1 = s0 + W;                              // becomes the axis-2 result
   const DMat<T, P>& dmat = dm;
+  // fp32, P >= 9: matrix entries from the kernarg segment (line_apply_mem;
+  // measured p = 11 fp32 1.02 -> 0.99 ms at 48^3, p = 9 fp64 0.83 -> 0.85 ms)
+#if SFEM_DMAT_MEM
+#define SFEM_LINE_APPLY(TR, X, Y)                                             \
+  do {                                                                        \
+    if constexpr (P >= 9 && sizeof(T) == 4)                                   \
+      line_apply_mem<T, P, TR>(                                               \
+          (const SFEM_CONSTANT_AS DMat<T, P>*)((                              \
+              const SFEM_CONSTANT_AS char*)                                   \
+                  __builtin_amdgcn_kernarg_segment_ptr() +                    \
+              sizeof(HelmholtzParams<T>)),                                    \
+          X, Y);                                                              \
+    else                                                                      \
+      line_apply<T, P, TR>(dmat, X, Y);                                       \
+  } while (0)
+#else
+#define SFEM_LINE_APPLY(TR, X, Y) line_apply<T, P, TR>(dmat, X, Y)
+#endif
   // SCALAR: one component known at compile time (no component loop, so the
   // compiler has nothing to hoist out of it and spill)
   const int nc = SCALAR ? 1 : prm.ncomp;
@@ -910,7 +977,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
     }
     if (has_stiff) {
       T d0[P];   // derivative along axis 0 at (a, i, j)
-      line_apply<T, P, false>(dmat, ua, d0);
+      SFEM_LINE_APPLY(false, ua, d0);
       if (lane_ok) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
@@ -924,7 +991,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = line[m];
-        line_apply<T, P, false>(dmat, x, y);
+        SFEM_LINE_APPLY(false, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) line[m] = y[m];
       }
@@ -933,7 +1000,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = line[m * SB];
-        line_apply<T, P, false>(dmat, x, y);
+        SFEM_LINE_APPLY(false, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) line[m * SB] = y[m];
       }
@@ -977,7 +1044,7 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = line[m];
-        line_apply<T, P, true>(dmat, x, y);
+        SFEM_LINE_APPLY(true, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) line[m] = y[m];
       }
@@ -986,12 +1053,12 @@ helmholtz_kernel(HelmholtzParams<T> prm, DMat<T, P> dm) {
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = line[m * SB];
-        line_apply<T, P, true>(dmat, x, y);
+        SFEM_LINE_APPLY(true, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) line[m * SB] = y[m];
       }
       T dt0[P];
-      line_apply<T, P, true>(dmat, w0, dt0);
+      SFEM_LINE_APPLY(true, w0, dt0);
       __syncthreads();
       if (lane_ok) {
 #pragma unroll
