@@ -227,6 +227,8 @@ def main():
                        'interior elements')
   ap.add_argument('--jitter', type=float, default=0.0,
                   help='smooth mesh deformation amplitude (fraction of h)')
+  ap.add_argument('--graph', action='store_true',
+                  help='N=1: replay each CG iteration as one HIP graph launch')
   ap.add_argument('--dry-run', action='store_true',
                   help='rehearse launch, rendezvous, block build and one '
                        'interface exchange on CPU tensors (gloo) and print a '
@@ -329,6 +331,10 @@ def main():
                    reduce_fn=part.reduce_sum_)
   else:
     run = CGRunner(A, b, tol=0.0, atol=0.0, maxiter=10 ** 9)
+    if args.graph:
+      captured = run.capture()
+      if rank == 0 and not captured:
+        print('bench.py: graph capture failed, running eagerly', file=sys.stderr)
 
   def barrier():
     torch.cuda.synchronize()
