@@ -660,6 +660,16 @@ __device__ __forceinline__ const DMat<T, P>* kernarg_dmat(int offset = 0) {
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() carries a
+// workgroup-scope fence over all address spaces, i.e. s_waitcnt vmcnt(0): every
+// wave then also waits for the acknowledgement of its outstanding global stores
+// and atomics (~4 k cycles under load) although the barrier only protects LDS.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Orders LDS traffic among the lanes of ONE wave: no instruction (LDS executes
 // a wave's operations in order), only a fence for the compiler.
 __device__ __forceinline__ void wave_sync() {

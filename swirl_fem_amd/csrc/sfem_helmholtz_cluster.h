@@ -40,6 +40,14 @@
 #pragma once
 #include "sfem_helmholtz.h"
 
+#ifndef SFEM_CL_LDS_BARRIER
+#define SFEM_CL_LDS_BARRIER 1
+#endif
+#if SFEM_CL_LDS_BARRIER
+#define SFEM_CL_BARRIER() lds_barrier()
+#else
+#define SFEM_CL_BARRIER() __syncthreads()
+#endif
 #ifndef SFEM_CL_SIZE
 #define SFEM_CL_SIZE 8
 #endif
@@ -166,7 +174,7 @@ helmholtz_cluster_kernel(DMat<T, P> dm, HelmholtzParams<T> prm,
       for (int a = 1; a < P - 1; ++a)
         ua[a] = ug[(int64_t)(enc[a] & SFEM_IDX_MASK) * ns];
     }
-    __syncthreads();
+    SFEM_CL_BARRIER();
     if (active) {
       ua[0] = strip[enc[0] & SFEM_IDX_MASK];
       ua[P - 1] = strip[enc[P - 1] & SFEM_IDX_MASK];
@@ -175,7 +183,7 @@ helmholtz_cluster_kernel(DMat<T, P> dm, HelmholtzParams<T> prm,
 #pragma unroll
       for (int a = 1; a < P - 1; ++a) ua[a] = strip[enc[a] & SFEM_IDX_MASK];
     }
-    __syncthreads();
+    SFEM_CL_BARRIER();
     // the strip now collects the sums
 #pragma unroll
     for (int m = 0; m < KPT; ++m) {
@@ -204,7 +212,7 @@ helmholtz_cluster_kernel(DMat<T, P> dm, HelmholtzParams<T> prm,
       for (int a = 1; a < P - 1; ++a)
         og[(int64_t)(enc[a] & SFEM_IDX_MASK) * ns] = acc[a];
     }
-    __syncthreads();   // the strip is cleared
+    SFEM_CL_BARRIER();   // the strip is cleared
     if (active) {      // ds_add: LDS only
       unsafeAtomicAdd(&strip[enc[0] & SFEM_IDX_MASK], acc[0]);
       unsafeAtomicAdd(&strip[enc[P - 1] & SFEM_IDX_MASK], acc[P - 1]);
@@ -214,7 +222,7 @@ helmholtz_cluster_kernel(DMat<T, P> dm, HelmholtzParams<T> prm,
       for (int a = 1; a < P - 1; ++a)
         unsafeAtomicAdd(&strip[enc[a] & SFEM_IDX_MASK], acc[a]);
     }
-    __syncthreads();
+    SFEM_CL_BARRIER();
     // nodes complete inside the cluster: plain stores; cluster surface: HBM
     // atomics, in ascending node order (whole 64-byte lines per request)
 #pragma unroll
@@ -231,7 +239,7 @@ helmholtz_cluster_kernel(DMat<T, P> dm, HelmholtzParams<T> prm,
         }
       }
     }
-    if (k + 1 < nc) __syncthreads();
+    if (k + 1 < nc) SFEM_CL_BARRIER();
   }
   if (prm.dot_out) {
 #pragma unroll
