@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFEM_ABI_VERSION 3
+#define SFEM_ABI_VERSION 4
 
 enum { SFEM_F32 = 0, SFEM_F64 = 1 };
 enum {
@@ -194,7 +194,9 @@ int sfem_basis_eval_t(const void* c0, const void* c1, const void* interp1,
  *                         constant times the tensor quadrature weight.
  * `elem_list` (device int32, num_listed entries) restricts a launch to some
  * elements, so a mesh mixing the kinds is applied by one call per kind.       */
-enum { SFEM_GEO_POINT = 0, SFEM_GEO_AFFINE = 1, SFEM_GEO_MULTILINEAR = 3 };
+enum { SFEM_GEO_POINT = 0, SFEM_GEO_AFFINE = 1, SFEM_GEO_MULTILINEAR = 3,
+       SFEM_GEO_BOX = 5 /* affine with diagonal J^-1 J^-T (Cartesian boxes):  */
+                        /* facet-table applies only, needs `geo_const`        */ };
 
 int sfem_helmholtz_setup(const void* invjac, const void* jacdet,
                          const void* weights_nd /* (Q,) */, void* geo,
@@ -276,7 +278,37 @@ typedef struct sfem_helmholtz_args {
                                   /*   SFEM_IDX_SHARED | DIRICHLET bit | its  */
                                   /*   POSITION in the table, other slots     */
                                   /*   id | DIRICHLET bit; elem_list unused   */
+  /* apply, 3D, P = 6..8: compact connectivity (NULL = off, `enc` is then     */
+  /* required).  (E, 27, 4) int32 from sfem_facet_table_build; every listed   */
+  /* element must have qualified there.  `enc`, `shared_order` are not read.  */
+  /* Needs node_stride = 1 (scalar or component-major fields).                */
+  const int32_t* facet_table;
+  const void* geo_const;  /* (E, 8) from sfem_helmholtz_setup_affine: needed  */
+                          /*   with facet_table for SFEM_GEO_AFFINE / _BOX    */
 } sfem_helmholtz_args;
+
+/* Compact connectivity of refiner-numbered meshes (reference numbering:
+ * core/mesh_refiner.py:143-251: the interior nodes of every premesh facet are
+ * one contiguous block, read through a cube orientation).  For element e and
+ * facet f = 9 cls(a) + 3 cls(i) + cls(j), cls = 0 (index 0) / 1 (interior) /
+ * 2 (index P-1), table[e][f] = { id0 | SFEM_IDX_* flags, sa, si, sj } with
+ *   elements[e][a, i, j] = id0 + sa (a - 1) + si (i - 1) + sj (j - 1)
+ * for every node of the facet (strides of fixed directions are 0).  ok[e] = 1
+ * iff all P^3 ids of the element, the Dirichlet flag and the SHARED flag
+ * (multiplicity > 1) of every node agree with its table; other elements must
+ * be applied through `enc`.  elements (E, P^3), ndim = 3, 2 <= P <= 12.       */
+int sfem_facet_table_build(const int32_t* elements, const uint8_t* dirichlet,
+                           const int32_t* multiplicity, int32_t* table,
+                           uint8_t* ok, int64_t num_elements,
+                           int64_t num_nodes, int P, sfem_stream_t stream);
+
+/* geo_elem (E, 24) of affine elements -> geo_const (E, 8) =
+ * { G00, G01, G02, G11, G12, G22, detJ, box } with G = detJ J^-1 J^-T (no
+ * quadrature weight) and box = 1 when |G01|, |G02|, |G12| <= box_tol *
+ * max(G00, G11, G22) (the element may then be applied as SFEM_GEO_BOX).      */
+int sfem_helmholtz_setup_affine(const void* geo_elem, void* geo_const,
+                                int64_t num_elements, double box_tol,
+                                int dtype, sfem_stream_t stream);
 
 /* cluster_size and max_shared (table entries per cluster) the cluster kernels
  * of (P, dtype) were compiled for; SFEM_EUNSUPPORTED outside P = 4..8.       */

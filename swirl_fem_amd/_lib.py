@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SFEM_LIB: another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get('SFEM_LIB') or os.path.join(_HERE, 'libsfem_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SFEM_F32, SFEM_F64 = 0, 1
 SFEM_CG_NSCALARS_NAMED = 16
@@ -40,6 +40,7 @@ class HelmholtzArgs(ctypes.Structure):
       ('shared_order', c_ptr), ('shared_stride', c_i32),
       ('cluster_elems', c_ptr), ('cluster_offsets', c_ptr),
       ('cluster_nodes', c_ptr), ('num_clusters', c_i64),
+      ('facet_table', c_ptr), ('geo_const', c_ptr),
   ]
 
 
@@ -59,7 +60,7 @@ class StokesArgs(ctypes.Structure):
   ]
 
 
-GEO_POINT, GEO_AFFINE, GEO_MULTILINEAR = 0, 1, 3
+GEO_POINT, GEO_AFFINE, GEO_MULTILINEAR, GEO_BOX = 0, 1, 3, 5
 
 # name -> argument types (all functions return int unless noted)
 SIGNATURES = {
@@ -96,6 +97,9 @@ SIGNATURES = {
     'sfem_helmholtz_setup_multilinear': [c_ptr, c_ptr, c_i64, c_i32, c_i32,
                                          c_i32, c_ptr],
     'sfem_helmholtz_local': [ctypes.POINTER(HelmholtzArgs), c_ptr],
+    'sfem_facet_table_build': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
+                               c_i32, c_ptr],
+    'sfem_helmholtz_setup_affine': [c_ptr, c_ptr, c_i64, c_dbl, c_i32, c_ptr],
     'sfem_helmholtz_cluster_limits': [c_i32, c_i32, ctypes.POINTER(c_i32),
                                       ctypes.POINTER(c_i32)],
     'sfem_dot': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],

@@ -378,6 +378,36 @@ def helmholtz_setup_multilinear(elem_coords, ndim, P):
   return geo_elem
 
 
+def facet_table(elements, dirichlet_u8, multiplicity, P):
+  """Compact connectivity (`sfem_facet_table_build`): `(E, 27, 4)` int32
+  table and the `(E,)` bool mask of the elements it describes exactly."""
+  elements = _idx(elements)
+  dev = _dev(elements, dirichlet_u8, multiplicity)
+  E = elements.shape[0]
+  tab = torch.empty((E, 27, 4), dtype=torch.int32, device=dev)
+  ok = torch.empty((E,), dtype=torch.uint8, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_facet_table_build(
+        _ptr(elements), _ptr(dirichlet_u8), _ptr(multiplicity), _ptr(tab),
+        _ptr(ok), E, multiplicity.shape[0], P, _stream(dev)),
+        'sfem_facet_table_build')
+  return tab, ok != 0
+
+
+def helmholtz_setup_affine(geo_elem, box_tol):
+  """(E, 24) coefficients of affine elements -> (E, 8) constants
+  (`sfem_helmholtz_setup_affine`); column 7 flags Cartesian boxes."""
+  geo_elem = geo_elem.contiguous()
+  dev = _dev(geo_elem)
+  E = geo_elem.shape[0]
+  out = torch.empty((E, 8), dtype=geo_elem.dtype, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_helmholtz_setup_affine(
+        _ptr(geo_elem), _ptr(out), E, float(box_tol), _dtype_code(geo_elem),
+        _stream(dev)), 'sfem_helmholtz_setup_affine')
+  return out
+
+
 def _host(a, dtype):
   np_dt = np.float64 if dtype == torch.float64 else np.float32
   return None if a is None else np.ascontiguousarray(a, dtype=np_dt)
@@ -408,6 +438,9 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
   cl = part.get('cluster') if enc is not None else None
   if cl is not None:
     enc, so = cl.enc, None
+  ft = part.get('facet_table') if enc is not None else None
+  if ft is not None:
+    so = None
   return _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),
       geo=_dptr(part.get('geo')), geo_elem=_dptr(part.get('geo_elem')),
@@ -426,7 +459,9 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       cluster_elems=_dptr(cl.elems if cl is not None else None),
       cluster_offsets=_dptr(cl.offsets if cl is not None else None),
       cluster_nodes=_dptr(cl.nodes if cl is not None else None),
-      num_clusters=0 if cl is None else cl.num_clusters)
+      num_clusters=0 if cl is None else cl.num_clusters,
+      facet_table=_dptr(ft),
+      geo_const=_dptr(part.get('geo_const') if ft is not None else None))
 
 
 _CLUSTER_LIMITS = {}
@@ -448,6 +483,12 @@ def helmholtz_cluster_limits(P, dtype):
 def helmholtz_kernel_name(real, P, ndim, scalar, geo_mode, part, mass):
   """Mirror of `launch_helmholtz`'s choice (csrc/sfem_helmholtz.h)."""
   b = lambda v: 'true' if v else 'false'
+  if part.get('facet_table') is not None:
+    if geo_mode == 5:
+      return 'sfem::helmholtz_box_kernel<%s, %d, %s, %s, ' % (
+          real, P, b(mass), b(scalar))
+    return 'sfem::helmholtz_facet_kernel<%s, %d, %d, %s, %s, ' % (
+        real, P, geo_mode, b(mass), b(scalar))
   if (real == 'float' and P == 12 and ndim == 3 and scalar and
       geo_mode in (1, 3) and part.get('cluster') is None and
       not part.get('colored') and os.environ.get('SFEM_MFMA', '0') == '1'):

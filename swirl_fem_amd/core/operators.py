@@ -92,7 +92,55 @@ def classify_geometry(fespace):
   return kind, coef
 
 
-_GEO_POINT, _GEO_AFFINE, _GEO_MULTILINEAR = 0, 1, 3
+_GEO_POINT, _GEO_AFFINE, _GEO_MULTILINEAR, _GEO_BOX = 0, 1, 3, 5
+FACET_P = (6, 7, 8)           # orders the facet-table kernels are compiled for
+BOX_TOL = {torch.float64: 1e-13, torch.float32: 5e-7}
+
+
+def _facet_parts(fespace, parts, mask, multiplicity, coef):
+  """`parts` re-expressed on compact connectivity (`sfem_facet_table_build`):
+  elements whose index row is 27 affine facet maps (every `refine_premesh`
+  mesh, reference core/mesh_refiner.py:143-251) are applied from their
+  432-byte table, affine ones with a diagonal metric as boxes; the remaining
+  elements keep their index rows.  None if no element qualifies."""
+  mesh = fespace.mesh
+  E = mesh.num_elements
+  tab, ok = _ops.facet_table(mesh.elements, mask, multiplicity,
+                             mesh.gridpoints_1d.num_points)
+  if not bool(ok.any()):
+    return None
+  every = torch.arange(E, device=ok.device)
+  cst = None
+  out = []
+
+  def add(part, ids, mode, facet):
+    if ids.numel() == 0:
+      return
+    new = {k: v for k, v in part.items() if k != 'elem_list'}
+    new['geo_mode'] = mode
+    if ids.numel() < E:
+      new['elem_list'] = ids.to(torch.int32).contiguous()
+    if facet:
+      new.pop('shared_order', None)
+      new['facet_table'] = tab
+      new['geo_const'] = cst
+    out.append(new)
+
+  use_box = os.environ.get('SFEM_BOX', '1') != '0'
+  for part in parts:
+    ids = every if 'elem_list' not in part else part['elem_list'].long()
+    good = ok[ids]
+    mode = part['geo_mode']
+    if mode == _GEO_AFFINE:
+      if cst is None:
+        cst = _ops.helmholtz_setup_affine(coef, BOX_TOL[fespace.dtype])
+      box = (cst[ids, 7] != 0) & good if use_box else torch.zeros_like(good)
+      add(part, ids[box], _GEO_BOX, True)
+      add(part, ids[good & ~box], _GEO_AFFINE, True)
+    else:
+      add(part, ids[good], mode, True)
+    add(part, ids[~good], mode, False)
+  return out
 
 
 def _cluster_limits(fespace):
@@ -131,6 +179,9 @@ class HelmholtzOperator:
   num_affine: int = 0
   num_multilinear: int = 0
   num_curved: int = 0
+  # the same launches on compact connectivity (scalar / component-major
+  # fields), or None: see `_facet_parts`
+  facet_parts: list | None = None
 
   @classmethod
   def create(cls, fespace, dirichlet_mask=None, geometry='auto',
@@ -245,13 +296,18 @@ class HelmholtzOperator:
       so = shared_slot_order(enc)
       if so is not None:
         parts = [dict(part, shared_order=so) for part in parts]
+    facet_parts = None
+    if (assembly == 'atomic' and mesh.ndim == 3 and
+        mesh.gridpoints_1d.num_points in FACET_P and
+        os.environ.get('SFEM_FACET', '1') != '0'):
+      facet_parts = _facet_parts(fespace, parts, mask, plan.multiplicity, coef)
     host = {'dmat': fespace.interpolator._differentiation_matrix_1d(),
             'weights': np.asarray(fespace.quadrature.weights),
             'nodes': np.asarray(mesh.gridpoints_1d.node_values)}
     return cls(fespace=fespace, parts=parts, enc=enc, host=host,
                zero_range=zero_range, num_affine=counts[_GEO_AFFINE],
                num_multilinear=counts[_GEO_MULTILINEAR],
-               num_curved=counts[_GEO_POINT])
+               num_curved=counts[_GEO_POINT], facet_parts=facet_parts)
 
   def split(self, element_mask):
     """Two operators over the elements inside / outside `element_mask` (E,)
@@ -265,10 +321,10 @@ class HelmholtzOperator:
     if mask.shape != (E,):
       raise ValueError(f'expected an ({E},) element mask')
     clustered = any(p.get('cluster') is not None for p in self.parts)
-    halves = []
-    for keep in (mask, ~mask):
+
+    def restrict(part_list, keep):
       parts = []
-      for part in self.parts:
+      for part in part_list:
         part = {k: v for k, v in part.items() if k != 'cluster'}
         if 'elem_list' in part:
           lst = part['elem_list']
@@ -277,11 +333,18 @@ class HelmholtzOperator:
           lst = torch.nonzero(keep).reshape(-1).to(torch.int32)
         if lst.numel():
           parts.append(dict(part, elem_list=lst.contiguous()))
+      return parts
+
+    halves = []
+    for keep in (mask, ~mask):
+      parts = restrict(self.parts, keep)
       if clustered:     # each half clusters its own elements
         parts = _attach_clusters(
             self.fespace, self.enc,
             self.fespace.mesh.assembly_plan().multiplicity, parts)
-      halves.append(dataclasses.replace(self, parts=parts))
+      facet = (None if self.facet_parts is None
+               else restrict(self.facet_parts, keep))
+      halves.append(dataclasses.replace(self, parts=parts, facet_parts=facet))
     return tuple(halves)
 
   def apply(self, u, lambda0=0.0, lambda1=1.0, out=None, *, zero=True,
@@ -303,9 +366,17 @@ class HelmholtzOperator:
     if out is None:
       out = torch.empty_like(u)        # same (dense) memory layout as u
     return _ops.helmholtz_apply(
-        u, out, self.enc, self.parts, self.host, mesh.ndim,
+        u, out, self.enc, self._parts_for(u), self.host, mesh.ndim,
         mesh.gridpoints_1d.num_points, lambda0, lambda1,
         self.zero_range if zero else (0, 0), dot_out)
+
+  def _parts_for(self, u):
+    """Facet-table launches for scalar / component-major fields (the kernels
+    address node n of component k at n + k * stride), index rows otherwise."""
+    if self.facet_parts is not None and (
+        u.dim() == 1 or u.shape[-1] == 1 or _ops.is_component_major(u)):
+      return self.facet_parts
+    return self.parts
 
   def apply_local(self, u_local, lambda0=0.0, lambda1=1.0):
     """Element-local action (E, n[, nc]) -> (E, n[, nc]); no gather/scatter."""
@@ -326,7 +397,8 @@ class HelmholtzOperator:
     real = 'double' if self.fespace.dtype == torch.float64 else 'float'
     P = mesh.gridpoints_1d.num_points
     names = []
-    for part in self.parts:
+    for part in (self.parts if self.facet_parts is None
+                 else self.facet_parts):
       gm = part['geo_mode']
       names.append(_ops.helmholtz_kernel_name(
           real, P, mesh.ndim, ncomp == 1, gm, part, lambda0 != 0))

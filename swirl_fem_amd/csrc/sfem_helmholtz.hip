@@ -4,6 +4,7 @@
 
 #include "sfem_helmholtz_cluster.h"
 #include "sfem_helmholtz_mfma.h"
+#include "sfem_helmholtz_facet.h"
 
 namespace sfem {
 
@@ -114,6 +115,115 @@ helmholtz_setup_multilinear_kernel(const T* __restrict__ elem_coords,
   }
 }
 
+// geo_elem (24 multilinear coefficients, affine elements: only A1..A3 matter)
+// -> G = detJ J^-1 J^-T (upper triangle), detJ, box flag.
+template <typename T>
+__global__ void __launch_bounds__(256)
+helmholtz_setup_affine_kernel(const T* __restrict__ geo_elem,
+                              T* __restrict__ geo_const, int64_t num_elements,
+                              T box_tol) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= num_elements) return;
+  const T* A = geo_elem + e * 24;
+  T a0[3], a1[3], a2[3];
+  for (int c = 0; c < 3; ++c) { a0[c] = A[c]; a1[c] = A[3 + c]; a2[c] = A[6 + c]; }
+  const T c0[3] = {a1[1] * a2[2] - a1[2] * a2[1], a1[2] * a2[0] - a1[0] * a2[2],
+                   a1[0] * a2[1] - a1[1] * a2[0]};
+  const T c1[3] = {a2[1] * a0[2] - a2[2] * a0[1], a2[2] * a0[0] - a2[0] * a0[2],
+                   a2[0] * a0[1] - a2[1] * a0[0]};
+  const T c2[3] = {a0[1] * a1[2] - a0[2] * a1[1], a0[2] * a1[0] - a0[0] * a1[2],
+                   a0[0] * a1[1] - a0[1] * a1[0]};
+  const T det = a0[0] * c0[0] + a0[1] * c0[1] + a0[2] * c0[2];
+  const T inv = T(1) / det;
+  T* g = geo_const + e * 8;
+  g[0] = inv * (c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+  g[1] = inv * (c0[0] * c1[0] + c0[1] * c1[1] + c0[2] * c1[2]);
+  g[2] = inv * (c0[0] * c2[0] + c0[1] * c2[1] + c0[2] * c2[2]);
+  g[3] = inv * (c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+  g[4] = inv * (c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2]);
+  g[5] = inv * (c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
+  g[6] = det;
+  const T dmax = fmax(fabs(g[0]), fmax(fabs(g[3]), fabs(g[5])));
+  const T omax = fmax(fabs(g[1]), fmax(fabs(g[2]), fabs(g[4])));
+  g[7] = omax <= box_tol * dmax ? T(1) : T(0);
+}
+
+// ---------------------------------------------------------------- builder ---
+// One wave per element: fits the 27 affine maps to the element's index row and
+// verifies every slot, the Dirichlet flag and the shared flag against them.
+// tab[e] is written for every element; ok[e] = 1 iff the element qualifies.
+__global__ void __launch_bounds__(64)
+facet_table_kernel(const int32_t* __restrict__ elements,
+                   const uint8_t* __restrict__ dirichlet,
+                   const int32_t* __restrict__ multiplicity,
+                   int32_t* __restrict__ tab, uint8_t* __restrict__ ok,
+                   int64_t num_elements, int64_t num_nodes, int P) {
+  __shared__ int32_t ids[1728];   // P <= 12
+  __shared__ int32_t ent[27][4];
+  __shared__ int bad;
+  const int64_t e = blockIdx.x;
+  const int n = P * P * P, lane = threadIdx.x;
+  const int32_t* row = elements + e * n;
+  if (lane == 0) bad = 0;
+  for (int s = lane; s < n; s += 64) ids[s] = row[s];
+  __syncthreads();
+  auto cls = [P](int a) { return a == 0 ? 0 : (a == P - 1 ? 2 : 1); };
+  if (lane < 27) {
+    const int c[3] = {lane / 9, (lane / 3) % 3, lane % 3};
+    int o[3], inner[3];
+    bool exists = true;
+    for (int d = 0; d < 3; ++d) {
+      inner[d] = c[d] == 1;
+      o[d] = c[d] == 0 ? 0 : (c[d] == 1 ? 1 : P - 1);
+      if (inner[d] && P < 3) exists = false;
+    }
+    int32_t code = 0, sd[3] = {0, 0, 0};
+    if (exists) {
+      const int os = (o[0] * P + o[1]) * P + o[2];
+      const int32_t id0 = ids[os];
+      const int stride[3] = {P * P, P, 1};
+      for (int d = 0; d < 3; ++d)
+        if (inner[d] && P >= 4) sd[d] = ids[os + stride[d]] - id0;
+      if (id0 < 0 || id0 >= num_nodes) {
+        atomicOr(&bad, 1);
+      } else {
+        uint32_t v = (uint32_t)id0;
+        if (dirichlet && dirichlet[id0]) v |= SFEM_IDX_DIRICHLET;
+        if (multiplicity[id0] > 1) v |= SFEM_IDX_SHARED;
+        code = (int32_t)v;
+      }
+      // strides must fit the 24-bit multiplies of the kernels
+      for (int d = 0; d < 3; ++d)
+        if (sd[d] > 0x7FFFFF || sd[d] < -0x7FFFFF) atomicOr(&bad, 1);
+    }
+    ent[lane][0] = code; ent[lane][1] = sd[0]; ent[lane][2] = sd[1];
+    ent[lane][3] = sd[2];
+  }
+  __syncthreads();
+  for (int s = lane; s < n; s += 64) {
+    const int a = s / (P * P), i = (s / P) % P, j = s % P;
+    const int f = cls(a) * 9 + cls(i) * 3 + cls(j);
+    const uint32_t code = (uint32_t)ent[f][0];
+    const int32_t pred = (int32_t)(code & SFEM_IDX_MASK) + ent[f][1] * (a - 1) +
+                         ent[f][2] * (i - 1) + ent[f][3] * (j - 1);
+    const int32_t id = ids[s];
+    bool good = id == pred && id >= 0 && id < num_nodes;
+    if (good) {
+      const bool dir = dirichlet && dirichlet[id];
+      const bool sh = multiplicity[id] > 1;
+      good = dir == ((code & SFEM_IDX_DIRICHLET) != 0) &&
+             sh == ((code & SFEM_IDX_SHARED) != 0);
+    }
+    if (!good) atomicOr(&bad, 1);
+  }
+  __syncthreads();
+  if (lane < 27) {
+    int32_t* dst = tab + e * FACET_ROW + lane * 4;
+    for (int q = 0; q < 4; ++q) dst[q] = ent[lane][q];
+  }
+  if (lane == 0) ok[e] = bad ? 0 : 1;
+}
+
 struct HelmholtzCall {
   const void* u; void* out; const int32_t* enc; const void* geo;
   const void* geo_elem; const int32_t* geo_index; const int32_t* elem_list;
@@ -128,6 +238,9 @@ struct HelmholtzCall {
   const int32_t* cluster_offsets = nullptr;
   const uint32_t* cluster_nodes = nullptr;
   int64_t num_clusters = 0;
+  const int32_t* facet_table = nullptr;
+  const void* geo_const = nullptr;
+  int64_t num_nodes = 0;
 };
 
 template <typename T>
@@ -151,6 +264,19 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
                         c.num_clusters};
     return dispatch_helmholtz_cluster<T>(prm, cl, c.P, stream);
   }
+  if (c.facet_table) {
+    FacetParams<T> fp{};
+    fp.u = prm.u; fp.out = prm.out; fp.tab = c.facet_table;
+    fp.geo_const = (const T*)c.geo_const; fp.geo_elem = prm.geo_elem;
+    fp.geo = prm.geo; fp.geo_index = prm.geo_index;
+    fp.elem_list = prm.elem_list; fp.comp_stride = prm.comp_stride;
+    fp.ncomp = prm.ncomp; fp.lambda0 = prm.lambda0; fp.lambda1 = prm.lambda1;
+    fp.dot_out = prm.dot_out;
+    return dispatch_helmholtz_facet<T>(fp, c.P, c.geo_mode, c.num_elements,
+                                       c.num_nodes, prm.dmat_host,
+                                       prm.weights_host, prm.nodes_host,
+                                       stream);
+  }
   if constexpr (sizeof(T) == 4) {
     // p = 11 fp32: the contractions on the matrix cores, opt-in (SFEM_MFMA=1):
     // measured 1.25 vs 1.0 ms for the vector-ALU kernel at 48^3 elements
@@ -171,7 +297,8 @@ static int check_geometry(const char* who, int geo_mode, const void* geo,
                           const void* nodes) {
   if (geo_mode == SFEM_GEO_POINT) {
     SFEM_REQUIRE(geo, "%s: per-point geometry needs `geo`", who);
-  } else if (geo_mode == SFEM_GEO_AFFINE || geo_mode == SFEM_GEO_MULTILINEAR) {
+  } else if (geo_mode == SFEM_GEO_AFFINE || geo_mode == SFEM_GEO_MULTILINEAR ||
+             geo_mode == SFEM_GEO_BOX) {
     SFEM_REQUIRE(geo_elem && weights && nodes,
                  "%s: on-the-fly geometry needs geo_elem, weights and nodes",
                  who);
@@ -264,7 +391,10 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
     if (rc0) return rc0;
   }
   if (a->num_elements == 0) return SFEM_OK;
-  SFEM_REQUIRE(a->u && a->enc && a->dmat, "sfem_helmholtz_apply: null pointer");
+  SFEM_REQUIRE(a->u && (a->enc || a->facet_table) && a->dmat,
+               "sfem_helmholtz_apply: null pointer");
+  SFEM_REQUIRE(a->geo_mode != SFEM_GEO_BOX || a->facet_table,
+               "sfem_helmholtz_apply: SFEM_GEO_BOX needs a facet table");
   int rc = check_geometry("sfem_helmholtz_apply", a->geo_mode, a->geo,
                           a->geo_elem, a->weights, a->nodes);
   if (rc) return rc;
@@ -293,8 +423,67 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
     c.cluster_nodes = a->cluster_nodes;
     c.num_clusters = a->num_clusters;
   }
+  if (a->facet_table) {
+    SFEM_REQUIRE(a->ndim == 3 && facet_supported_p(a->P),
+                 "sfem_helmholtz_apply: facet tables are 3D, P = 6..8");
+    SFEM_REQUIRE(!a->colored && !a->cluster_elems,
+                 "sfem_helmholtz_apply: facet tables exclude colored / "
+                 "cluster assembly");
+    SFEM_REQUIRE(a->ncomp == 1 || a->node_stride == 1,
+                 "sfem_helmholtz_apply: facet tables need node_stride = 1");
+    SFEM_REQUIRE(a->geo_const || (a->geo_mode != SFEM_GEO_AFFINE &&
+                                  a->geo_mode != SFEM_GEO_BOX),
+                 "sfem_helmholtz_apply: affine / box facet applies need "
+                 "geo_const");
+    c.facet_table = a->facet_table;
+    c.geo_const = a->geo_const;
+    c.num_nodes = a->num_nodes;
+  }
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
+}
+
+int sfem_facet_table_build(const int32_t* elements, const uint8_t* dirichlet,
+                           const int32_t* multiplicity, int32_t* table,
+                           uint8_t* ok, int64_t num_elements,
+                           int64_t num_nodes, int P, sfem_stream_t stream) {
+  SFEM_REQUIRE(num_elements >= 0 && num_nodes >= 0 && P >= 2 && P <= 12,
+               "sfem_facet_table_build: bad sizes");
+  if (num_elements == 0) return SFEM_OK;
+  SFEM_REQUIRE(elements && multiplicity && table && ok,
+               "sfem_facet_table_build: null pointer");
+  SFEM_REQUIRE(num_elements <= 0x7fffffff,
+               "sfem_facet_table_build: too many elements");
+  hipLaunchKernelGGL(facet_table_kernel, dim3((unsigned)num_elements), dim3(64),
+                     0, as_stream(stream), elements, dirichlet, multiplicity,
+                     table, ok, num_elements, num_nodes, P);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_helmholtz_setup_affine(const void* geo_elem, void* geo_const,
+                                int64_t num_elements, double box_tol,
+                                int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(num_elements >= 0, "sfem_helmholtz_setup_affine: bad sizes");
+  if (num_elements == 0) return SFEM_OK;
+  SFEM_REQUIRE(geo_elem && geo_const,
+               "sfem_helmholtz_setup_affine: null pointer");
+  const unsigned grid = (unsigned)((num_elements + 255) / 256);
+  if (dtype == SFEM_F64)
+    hipLaunchKernelGGL(helmholtz_setup_affine_kernel<double>, dim3(grid),
+                       dim3(256), 0, as_stream(stream),
+                       (const double*)geo_elem, (double*)geo_const,
+                       num_elements, box_tol);
+  else if (dtype == SFEM_F32)
+    hipLaunchKernelGGL(helmholtz_setup_affine_kernel<float>, dim3(grid),
+                       dim3(256), 0, as_stream(stream), (const float*)geo_elem,
+                       (float*)geo_const, num_elements, (float)box_tol);
+  else {
+    set_error("sfem_helmholtz_setup_affine: unknown dtype %d", dtype);
+    return SFEM_EINVAL;
+  }
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
 }
 
 int sfem_helmholtz_cluster_limits(int P, int dtype, int* cluster_size,

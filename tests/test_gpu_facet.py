@@ -1,0 +1,219 @@
+"""GPU parity of the compact-connectivity (facet table) Helmholtz kernels
+(`csrc/sfem_helmholtz_facet.h`): table builder vs the index rows it replaces,
+operator vs the CPU oracle and vs the index-row kernels, 3D, P = 6..8.
+
+fp64 tolerance 1e-10 relative, fp32 3e-5 (BASELINE.json north_star: 1e-10 /
+1e-5 with the fp32 margin the other fused-kernel tests use).
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sfem_oracle as O
+from swirl_fem_amd import _lib, _ops
+from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+from swirl_fem_amd.core.fespace import FiniteElementSpace
+from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
+from swirl_fem_amd.core.mesh_refiner import refine_premesh
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+GLL = NodeType.GAUSS_LOBATTO_LEGENDRE
+TOL = {torch.float64: 1e-10, torch.float32: 3e-5}
+
+
+def dev(x, dtype=None):
+  t = torch.as_tensor(np.ascontiguousarray(x), device=DEV)
+  return t if dtype is None else t.to(dtype)
+
+
+def relerr(a, b):
+  a = a.detach().cpu().numpy().astype(np.float64)
+  return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def random_orientations(pm, rng):
+  """Random element order and one of the 48 vertex orderings per element."""
+  orients = [(perm, axes) for perm in itertools.permutations(range(3))
+             for r in range(4) for axes in itertools.combinations(range(3), r)]
+  el = []
+  for e in pm.elements[rng.permutation(pm.num_elements)]:
+    perm, axes = orients[rng.integers(len(orients))]
+    el.append(np.flip(e.reshape(2, 2, 2).transpose(perm), axes).reshape(-1))
+  return pm.replace(elements=np.array(el, dtype=np.int32))
+
+
+def make_mesh(n, P, mode, rng, rotate=False):
+  pm = unit_cube_mesh(n, ndim=3)
+  x = pm.node_coords.copy()
+  if mode == 'sheared':
+    x = x @ (np.eye(3) + 0.3 * rng.uniform(-1, 1, (3, 3))).T + 0.1
+  elif mode == 'jittered':
+    x = x + 0.1 / n * rng.uniform(-1, 1, x.shape)
+  elif mode == 'stretched':       # boxes of different sizes: still diagonal
+    x = x ** np.array([1.0, 1.5, 2.0])
+  pm = pm.replace(node_coords=x)
+  if rotate:
+    pm = random_orientations(pm, rng)
+  return refine_premesh(pm, Nodes1D.create(P, GLL))
+
+
+def reference(ofes, u, l0, l1, mask):
+  ul = ofes.gather(u)
+  loc = 0.0
+  if l0:
+    loc = loc + l0 * ofes.mass_local(ul)
+  if l1:
+    loc = loc + l1 * ofes.stiffness_local(ul)
+  out = ofes.scatter(loc)
+  if mask is not None:
+    keep = 1.0 - mask.astype(np.float64)
+    out = out * (keep if out.ndim == 1 else keep[:, None])
+  return out
+
+
+def table_ids(tab, P):
+  """The (E, P^3) index rows a table stands for, and its flag bits."""
+  tab = tab.cpu().numpy().astype(np.int64)
+  cls = lambda a: 0 if a == 0 else (2 if a == P - 1 else 1)
+  E = tab.shape[0]
+  ids = np.zeros((E, P, P, P), dtype=np.int64)
+  flags = np.zeros((E, P, P, P), dtype=np.int64)
+  for a, i, j in itertools.product(range(P), repeat=3):
+    ent = tab[:, cls(a) * 9 + cls(i) * 3 + cls(j)]
+    code = ent[:, 0] & 0xFFFFFFFF
+    ids[:, a, i, j] = ((code & 0x3FFFFFFF) + ent[:, 1] * (a - 1) +
+                       ent[:, 2] * (i - 1) + ent[:, 3] * (j - 1))
+    flags[:, a, i, j] = code >> 30
+  return ids.reshape(E, -1), flags.reshape(E, -1)
+
+
+@pytest.mark.parametrize('P', [3, 4, 6, 7, 8, 12])
+def test_facet_table_reproduces_the_index_rows(P):
+  rng = np.random.default_rng(P)
+  n = 2 if P > 8 else 3
+  rp = make_mesh(n, P, 'jittered', rng, rotate=True)
+  mesh = rp.finalize(device=DEV)
+  mult = mesh.assembly_plan().multiplicity
+  mask = mesh.physical_masks['boundary'].to(torch.uint8).contiguous()
+  tab, ok = _ops.facet_table(mesh.elements, mask, mult, P)
+  assert bool(ok.all())
+  ids, flags = table_ids(tab, P)
+  assert np.array_equal(ids, rp.elements)
+  enc = _ops.encode_elements(mesh.elements, mask, mult).cpu().numpy()
+  assert np.array_equal(flags, (enc.astype(np.int64) & 0xFFFFFFFF) >> 30)
+  # elements that are NOT 27 affine maps, or whose flags cut through a facet,
+  # must be refused (and only those)
+  el = rp.elements.copy()
+  el[1, [5, 6]] = el[1, [6, 5]]   # two nodes of one facet swapped (P = 3:
+                                  # of two one-node facets, still 27 maps)
+  el[2, 7] = -1                                 # padding slot
+  m2 = mask.clone()
+  inner = int(rp.elements[0].reshape(P, P, P)[0, 1, 1])   # a face-interior node
+  face = rp.elements[0].reshape(P, P, P)[0, 1:-1, 1:-1].reshape(-1)
+  only_one = P > 3 and not bool(mask[inner])
+  if only_one:
+    m2[inner] = 1
+  tab2, ok2 = _ops.facet_table(dev(el), m2, mult, P)
+  ok2 = ok2.cpu().numpy()
+  assert ok2[1] == (P == 3) and not ok2[2]
+  if only_one:      # every element that holds the re-flagged face is refused
+    holds = np.isin(rp.elements, face).any(axis=1)
+    assert not ok2[holds].any()
+    rest = ~holds
+    rest[[1, 2]] = False
+    assert ok2[rest].all()
+
+
+@pytest.mark.parametrize('P', [6, 7, 8])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_facet_helmholtz_matches_oracle(P, dtype, monkeypatch):
+  tol = TOL[dtype]
+  for mode, rotate in (('structured', False), ('stretched', True),
+                       ('sheared', True), ('jittered', True)):
+    rng = np.random.default_rng(100 * P + len(mode))
+    rp = make_mesh(2, P, mode, rng, rotate)
+    mesh = rp.finalize(device=DEV, dtype=dtype)
+    fes = FiniteElementSpace.create(
+        mesh, Quadrature1D.create_from_nodes_1d(Nodes1D.create(P, GLL)))
+    ofes = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'), (P, 'gll'))
+    bmask = mesh.physical_masks['boundary']
+    ops = {g: fes.helmholtz_operator(bmask, g)
+           for g in ('auto', 'multilinear', 'stored')}
+    monkeypatch.setenv('SFEM_FACET', '0')
+    from swirl_fem_amd.core import operators
+    plain = operators.HelmholtzOperator.create(fes, bmask, 'auto')
+    monkeypatch.delenv('SFEM_FACET')
+    assert plain.facet_parts is None
+    for g, op in ops.items():
+      assert op.facet_parts is not None, (mode, g)
+      assert all('facet_table' in p for p in op.facet_parts), (mode, g)
+    kinds = {p['geo_mode'] for p in ops['auto'].facet_parts}
+    if dtype == torch.float64:
+      want = {'structured': {_lib.GEO_BOX}, 'stretched': {_lib.GEO_BOX},
+              'sheared': {_lib.GEO_AFFINE},
+              'jittered': {_lib.GEO_MULTILINEAR}}[mode]
+      assert kinds == want, (mode, kinds)
+    mk = bmask.cpu().numpy()
+    for nc in (1, 3):
+      u = rng.standard_normal((mesh.num_nodes, nc))
+      uu = u[:, 0] if nc == 1 else u
+      ud = dev(uu, dtype) if nc == 1 else dev(u.T.copy(), dtype).t()
+      for l0, l1 in ((0.0, 1.0), (0.6, 1.4), (1.0, 0.0)):
+        ref = reference(ofes, uu, l0, l1, mk)
+        for g, op in ops.items():
+          got = op.apply(ud, l0, l1)
+          assert relerr(got, ref) < tol, (mode, g, nc, l0, l1)
+        assert relerr(plain.apply(ud, l0, l1), ref) < tol
+      # fused u . A u
+      ref = reference(ofes, uu, 0.0, 1.0, mk)
+      want, scale = float((uu * ref).sum()), float(np.abs(uu * ref).sum())
+      for g, op in ops.items():
+        parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
+                            device=DEV)
+        got = op.apply(ud, 0.0, 1.0, dot_out=parts)
+        assert relerr(got, ref) < tol
+        assert abs(float(parts.sum()) - want) <= 10 * tol * scale, (mode, g)
+    # interleaved (N, nc) fields keep the index-row kernels
+    u = rng.standard_normal((mesh.num_nodes, 2))
+    got = ops['auto'].apply(dev(u, dtype), 0.3, 1.0)
+    assert relerr(got, reference(ofes, u, 0.3, 1.0, mk)) < tol
+
+
+def test_facet_and_index_row_elements_in_one_operator():
+  """Elements the builder refuses (here: a Dirichlet mask that holds single
+  nodes of a face, and nothing else of it) fall back to the index rows; the
+  operator applies both groups and matches the oracle."""
+  P = 8
+  rng = np.random.default_rng(5)
+  rp = make_mesh(3, P, 'jittered', rng, rotate=True)
+  mesh = rp.finalize(device=DEV)
+  fes = FiniteElementSpace.create(
+      mesh, Quadrature1D.create_from_nodes_1d(Nodes1D.create(P, GLL)))
+  ofes = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'), (P, 'gll'))
+  mask = mesh.physical_masks['boundary'].cpu().numpy().copy()
+  pick = rng.choice(np.nonzero(~mask)[0], 5, replace=False)
+  mask[pick] = True
+  op = fes.helmholtz_operator(dev(mask))
+  n_facet = sum(p['elem_list'].numel() if 'elem_list' in p else
+                mesh.num_elements for p in op.facet_parts
+                if 'facet_table' in p)
+  assert 0 < n_facet < mesh.num_elements
+  assert any('facet_table' not in p for p in op.facet_parts)
+  u = rng.standard_normal(mesh.num_nodes)
+  for l0, l1 in ((0.0, 1.0), (0.5, 2.0)):
+    ref = reference(ofes, u, l0, l1, mask)
+    assert relerr(op.apply(dev(u), l0, l1), ref) < 1e-10
+  # split(): both halves keep their share of either group
+  half = torch.arange(mesh.num_elements, device=DEV) % 2 == 0
+  a, b = op.split(half)
+  out = a.apply(dev(u), 0.5, 2.0)
+  out = b.apply(dev(u), 0.5, 2.0, out=out, zero=False)
+  # owned nodes of `a` are plain stores in both halves: compare shared-safe sum
+  ra = reference(O.FESpace(rp.node_coords, rp.elements[::2], (P, 'gll'),
+                           (P, 'gll')), u, 0.5, 2.0, mask)
+  rb = reference(O.FESpace(rp.node_coords, rp.elements[1::2], (P, 'gll'),
+                           (P, 'gll')), u, 0.5, 2.0, mask)
+  assert relerr(out, ra + rb) < 1e-10
