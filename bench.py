@@ -38,24 +38,41 @@ def algorithmic_bytes_per_apply(E, n, N, sizeof=8, ngeo=6):
   return 4 * E * n + sizeof * N + ngeo * sizeof * E * n + sizeof * N
 
 
-def kernel_bytes_per_apply(E, n, N, sizeof, ngeo, num_onthefly, num_stored):
-  """Bytes the timed launch HAS to move: idx 4 E n + u s N + out s N + the
-  geometry it actually reads -- 24 reals per affine / multilinear element
-  (their factors are evaluated in registers), `ngeo` reals per point only for
-  elements with stored factors."""
-  return (4 * E * n + 2 * sizeof * N + 24 * sizeof * num_onthefly +
-          ngeo * sizeof * n * num_stored)
+# Single-GPU time of ONE CG iteration on the fixed meshes the N > 1 runs
+# split (`--scaling strong`) or assemble (`--scaling weak`: N blocks of
+# --elems^3), measured on one MI355X and committed under profiles/: the first
+# real scaling record can then be read as the speed-up north_star asks for.
+STRONG_REF = {   # (global elements per direction, p, dtype) -> (ms, source)
+    (128, 7, 'f64'): (15.7, 'profiles/r01_bench_n128_single_gpu.json'),
+}
 
 
-TRAFFIC_FILE = 'profiles/traffic_r02.json'
+TRAFFIC_FILE = 'profiles/traffic_r03.json'
+
+
+def kernel_source_hash():
+  """sha256 over the kernel sources (csrc/*.h, *.hip, include/sfem.h): the
+  profile in TRAFFIC_FILE counts only for the build it was taken on."""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  files = sorted(glob.glob(os.path.join(ROOT, 'swirl_fem_amd', 'csrc', '*.h')) +
+                 glob.glob(os.path.join(ROOT, 'swirl_fem_amd', 'csrc', '*.hip')) +
+                 [os.path.join(ROOT, 'include', 'sfem.h')])
+  for f in files:
+    h.update(os.path.basename(f).encode())
+    with open(f, 'rb') as fh:
+      h.update(fh.read())
+  return h.hexdigest()[:16]
 
 
 def measured_traffic(n, p, dtype, geometry, jitter):
-  """(HBM bytes per launch of the dominant kernel, git sha of the build they
-  were measured on) from the rocprofv3 PMC passes of this exact command
-  (`scripts/pmc_traffic.sh` writes TRAFFIC_FILE), or (None, None).  PMC
-  counters cannot be read from inside the process, so the figure is a
-  profile of an earlier run of the same command, stamped with its commit."""
+  """(HBM bytes per launch of the dominant kernel, source hash of the build
+  they were measured on) from the rocprofv3 PMC passes of this exact command
+  (`scripts/collect_profiles3.py` writes TRAFFIC_FILE), or (None, None) --
+  also when the kernel sources have changed since (`kernel_source_hash`).
+  PMC counters cannot be read from inside the process, so the figure is a
+  profile of an earlier run of the same command on the same sources."""
   key = 'n%d_p%d_%s_%s' % (n, p, dtype, 'stored' if geometry == 'stored'
                            else 'auto')
   if jitter:
@@ -65,9 +82,9 @@ def measured_traffic(n, p, dtype, geometry, jitter):
       entry = json.load(f).get(key)
   except (OSError, ValueError):
     return None, None
-  if entry is None:
+  if entry is None or entry.get('src_hash') != kernel_source_hash():
     return None, None
-  return entry['bytes'], entry.get('git_sha')
+  return entry['bytes'], entry.get('src_hash')
 
 
 def block_grid(world):
@@ -100,12 +117,21 @@ def cpu_baseline(P, budget_s=12.0, ne=32):
     rng = np.random.default_rng(0)
     b = torch.from_numpy((1.0 - mask) * rng.standard_normal(rp.num_nodes))
     _, iters, el = ref.cg_iterations(b, budget_s=budget_s)
+    # "also report the sum-factorised CPU variant" (the same CG
+    # with the element gradient contracted axis by axis)
+    _, it_sf, el_sf = ref.cg_iterations(b, budget_s=budget_s / 2,
+                                        sum_factorised=True)
     threads = torch.get_num_threads()
   finally:
     torch.set_num_threads(saved)
   return {
       'value': rp.num_nodes * iters / el / 1e9, 'unit': 'GDOF/s',
       'cores': threads, 'kind': 'port',
+      'sum_factorised': {
+          'value': rp.num_nodes * it_sf / el_sf / 1e9, 'unit': 'GDOF/s',
+          'sample': f'same mesh and CG, element gradient by three 1D '
+                    f'contractions (torch-CPU einsum, {threads} threads): '
+                    f'{it_sf} iterations in {el_sf:.1f} s'},
       'sample': f'{ne}^3 hex elements p={P - 1} ({rp.num_nodes} DOFs), {iters} '
                 f'CG iterations in {el:.1f} s of the reference algorithm '
                 f'(dense-Kronecker element matrices as torch-CPU GEMMs on '
@@ -265,12 +291,24 @@ def main():
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:
+    import datetime
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if args.backend == 'nccl':
-      dist.init_process_group('nccl', rank=rank, world_size=world,
-                              device_id=device)
-    else:
-      dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+      # a rendezvous that does not complete in two minutes is a broken launch:
+      # fail with the rank and device instead of sitting out the driver's limit
+      if args.backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=device,
+                                timeout=datetime.timedelta(seconds=120))
+      else:
+        dist.init_process_group('gloo', rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=120))
+    except Exception as exc:    # pylint: disable=broad-except
+      print(f'bench.py: rank {rank}/{world} on {device} '
+            f'({args.backend}, MASTER_ADDR={os.environ.get("MASTER_ADDR")}, '
+            f'MASTER_PORT={os.environ.get("MASTER_PORT")}) could not join the '
+            f'process group: {exc!r}', file=sys.stderr, flush=True)
+      raise SystemExit(3)
 
   P = args.p + 1
   grid = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
@@ -416,6 +454,8 @@ def main():
     op_g = fes.helmholtz_operator(mesh.physical_masks.get('boundary'),
                                   geometry='stored')
     general = time_apply(op_g)
+    stored_bytes = op_g.bytes_per_apply(args.mass_coeff)
+    stored_kernel = op_g.kernel_name(args.mass_coeff, 1.0)
     del op_g
   # device stream figure beside the vendor peak: y = a x + b y over
   # N-vectors, 3 passes
@@ -434,13 +474,22 @@ def main():
   ngeo = 7 if args.mass_coeff else 6
   model_bytes = algorithmic_bytes_per_apply(E, n, N_local, sizeof=sizeof,
                                             ngeo=ngeo)
-  kernel_bytes = kernel_bytes_per_apply(
-      E, n, N_local, sizeof, ngeo, op.num_affine + op.num_multilinear,
-      op.num_curved)
+  kernel_bytes = op.bytes_per_apply(args.mass_coeff)
   achieved = kernel_bytes / (kern_ms * 1e-3) / 1e9
   traffic, traffic_sha = measured_traffic(args.n, args.p, args.dtype,
                                           args.geometry, args.jitter)
   passes = run.vector_passes if hasattr(run, 'vector_passes') else 8
+  # the same GLOBAL mesh on one GPU (committed measurement), so that an N > 1
+  # line reads directly as north_star's strong-scaling speed-up
+  strong_ref = None
+  if world > 1 and not periodic_dims and not args.jitter:
+    gdim = (args.n if args.scaling == 'strong'
+            else (args.n * grid_b[0] if len(set(grid_b)) == 1 else None))
+    ref = STRONG_REF.get((gdim, args.p, args.dtype))
+    if ref is not None:
+      strong_ref = {'global_elements': gdim ** 3, 'n_gpus': 1,
+                    'ms_per_step': ref[0], 'source': ref[1],
+                    'speedup_vs_strong_ref': ref[0] / ms_per_step}
 
   if rank == 0:
     res = {
@@ -469,6 +518,7 @@ def main():
                         '(rehearsal)') if world > 1 else None,
             'world_size_seen': dist.get_world_size() if world > 1 else 1,
             'per_rank': per_rank,
+            'strong_ref': strong_ref,
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
             'apply_ms': apply_ms, 'setup_s': setup_s,
             'geometry': ('%s: %d affine + %d multilinear elements (factors '
@@ -483,19 +533,23 @@ def main():
             'traffic': traffic,
             'traffic_profiled_at': traffic_sha,
             'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
-                              'of this command on the commit named in '
-                              'traffic_profiled_at (%s; FETCH_SIZE doubled as '
-                              'MI355X_MICROARCH.md prescribes); null if this '
-                              'workload was not profiled' % TRAFFIC_FILE,
+                              'of this command (%s; FETCH_SIZE doubled as '
+                              'MI355X_MICROARCH.md prescribes); null when the '
+                              'workload was not profiled or the kernel sources '
+                              '(sha256 in traffic_profiled_at) have changed '
+                              'since' % TRAFFIC_FILE,
             'kernel': op.kernel_name(args.mass_coeff, 1.0),
             'kernel_ms': kern_ms,
             'kernel_ms_covers': 'one apply as the solver issues it: the fused '
                                 'kernel plus the clearing of the atomically '
                                 'accumulated node range it needs, if any',
             'bytes_per_launch': kernel_bytes,
-            'bytes_model': 'idx 4 E n + u s N + out s N + 24 reals per affine '
-                           '/ multilinear element + %d reals per point of '
-                           'elements with stored factors' % ngeo,
+            'bytes_model': 'u s N + out s N + connectivity (432 B per element '
+                           'from a facet table, + 4 B on a chain list; 4 n + '
+                           '2 S per element on index rows) + geometry (64 B '
+                           'per affine / box element, 24 reals per multilinear '
+                           'one, %d reals per point where factors are stored): '
+                           'HelmholtzOperator.bytes_per_apply' % ngeo,
             'measured_stream_peak': stream_gbs,
             'frac_of_measured_stream': achieved / stream_gbs,
             # NOT an HBM fraction: the SURVEY 8(d) stored-6-factor model
@@ -521,15 +575,16 @@ def main():
                 'the vectors anyway); model_gdofs_ratio is against SURVEY '
                 "8(d)'s stored-factor apply + 11 passes" % passes}
     if general is not None:
-      stored_bytes = kernel_bytes_per_apply(E, n, N_local, sizeof, ngeo, 0, E)
       res['roofline_stored_factors'] = {
           'bound': 'hbm', 'achieved': stored_bytes / (general * 1e-3) / 1e9,
           'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
           'frac': stored_bytes / (general * 1e-3) / 1e9 / HBM_PEAK_GBS,
           'kernel_ms': general, 'bytes_per_launch': stored_bytes,
-          'kernel': 'same launch with geometry=stored (GM=0): every element '
-                    'reads its %d factors per point, as curved elements do '
-                    '(= the SURVEY 8(d) byte model)' % ngeo}
+          'kernel': stored_kernel,
+          'note': 'the same mesh with geometry=stored: every element reads '
+                  'its %d factors per point, as curved elements do (the '
+                  'SURVEY 8(d) byte model, with the connectivity this build '
+                  'reads instead of 4 E n)' % ngeo}
     if world == 1 and not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(P, ne=min(32, args.n) if args.p <= 7 else min(12, args.n))
     else:

@@ -285,6 +285,18 @@ typedef struct sfem_helmholtz_args {
   const int32_t* facet_table;
   const void* geo_const;  /* (E, 8) from sfem_helmholtz_setup_affine: needed  */
                           /*   with facet_table for SFEM_GEO_AFFINE / _BOX    */
+  /* facet_table applies of SCALAR fields: the elements as chains (NULL / 0 = */
+  /* one workgroup per listed element).  Segment s is the elements            */
+  /* chain_elems[chain_offsets[s] .. chain_offsets[s+1]); inside a segment    */
+  /* the face a = P-1 of every element IS the face a = 0 of the next, node    */
+  /* for node: elements[e][(P-1) P^2 + t] == elements[next][t], t < P^2.      */
+  /* One wave walks a segment and carries that face in registers (gathered    */
+  /* once, summed before it is written: its interior needs no atomic).  The   */
+  /* segments must hold every element of the launch exactly once; elem_list   */
+  /* is not read.                                                             */
+  const int32_t* chain_offsets;   /* (num_chains + 1,)                        */
+  const int32_t* chain_elems;     /* (chain_offsets[num_chains],)             */
+  int64_t num_chains;
 } sfem_helmholtz_args;
 
 /* Compact connectivity of refiner-numbered meshes (reference numbering:

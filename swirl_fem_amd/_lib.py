@@ -41,6 +41,7 @@ class HelmholtzArgs(ctypes.Structure):
       ('cluster_elems', c_ptr), ('cluster_offsets', c_ptr),
       ('cluster_nodes', c_ptr), ('num_clusters', c_i64),
       ('facet_table', c_ptr), ('geo_const', c_ptr),
+      ('chain_offsets', c_ptr), ('chain_elems', c_ptr), ('num_chains', c_i64),
   ]
 
 

@@ -439,8 +439,11 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
   if cl is not None:
     enc, so = cl.enc, None
   ft = part.get('facet_table') if enc is not None else None
+  ch = None
   if ft is not None:
     so = None
+    if not vec and os.environ.get('SFEM_CHAIN', '1') != '0':
+      ch = part.get('chains')        # (offsets, elems) int32 device tensors
   return _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),
       geo=_dptr(part.get('geo')), geo_elem=_dptr(part.get('geo_elem')),
@@ -461,7 +464,10 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       cluster_nodes=_dptr(cl.nodes if cl is not None else None),
       num_clusters=0 if cl is None else cl.num_clusters,
       facet_table=_dptr(ft),
-      geo_const=_dptr(part.get('geo_const') if ft is not None else None))
+      geo_const=_dptr(part.get('geo_const') if ft is not None else None),
+      chain_offsets=_dptr(ch[0] if ch is not None else None),
+      chain_elems=_dptr(ch[1] if ch is not None else None),
+      num_chains=0 if ch is None else ch[0].numel() - 1)
 
 
 _CLUSTER_LIMITS = {}
@@ -484,11 +490,14 @@ def helmholtz_kernel_name(real, P, ndim, scalar, geo_mode, part, mass):
   """Mirror of `launch_helmholtz`'s choice (csrc/sfem_helmholtz.h)."""
   b = lambda v: 'true' if v else 'false'
   if part.get('facet_table') is not None:
-    if geo_mode == 5:
-      return 'sfem::helmholtz_box_kernel<%s, %d, %s, %s, ' % (
-          real, P, b(mass), b(scalar))
-    return 'sfem::helmholtz_facet_kernel<%s, %d, %d, %s, %s, ' % (
-        real, P, geo_mode, b(mass), b(scalar))
+    elem = ('sfem::BoxElem<%s, %d, %s>' % (real, P, b(mass)) if geo_mode == 5
+            else 'sfem::FacetElem<%s, %d, %d, %s>' % (real, P, geo_mode,
+                                                     b(mass)))
+    if (scalar and part.get('chains') is not None and
+        os.environ.get('SFEM_CHAIN', '1') != '0'):
+      return 'sfem::helmholtz_chain_kernel<%s, %d, %s, ' % (real, P, elem)
+    return 'sfem::helmholtz_facet_kernel<%s, %d, %s, %s, ' % (
+        real, P, elem, b(scalar))
   if (real == 'float' and P == 12 and ndim == 3 and scalar and
       geo_mode in (1, 3) and part.get('cluster') is None and
       not part.get('colored') and os.environ.get('SFEM_MFMA', '0') == '1'):

@@ -97,6 +97,60 @@ FACET_P = (6, 7, 8)           # orders the facet-table kernels are compiled for
 BOX_TOL = {torch.float64: 1e-13, torch.float32: 5e-7}
 
 
+def facet_chains(elements, ids, P, seg_len):
+  """Walks the elements `ids` (int64, device) as chains for the chain launches
+  of the facet kernels (`sfem_helmholtz_args.chain_offsets`): element y follows
+  x when the face a = P-1 of x is the face a = 0 of y, node for node in the
+  lane layout, i.e. `elements[x, (P-1) P^2 + t] == elements[y, t]` for all
+  t < P^2 (on a refiner mesh: the neighbour across that face, met with the
+  same orientation).  Chains are cut into segments of at most `seg_len`
+  elements.  Returns (offsets (S + 1,), elems) int32; elements without a
+  neighbour of that kind are segments of their own."""
+  m = ids.numel()
+  dev = ids.device
+  n2 = P * P
+  first = elements[ids, :n2].to(torch.int64)
+  last = elements[ids, (P - 1) * n2:].to(torch.int64)
+  gen = torch.Generator(device='cpu').manual_seed(1234)
+  wts = torch.randint(1, 1 << 31, (n2,), generator=gen).to(dev)
+  hf, hl = (first * wts).sum(1), (last * wts).sum(1)
+  hs, order = torch.sort(hf)
+  pos = torch.searchsorted(hs, hl).clamp(max=m - 1)
+  cand = order[pos]
+  me = torch.arange(m, device=dev)
+  ok = (hs[pos] == hl) & (cand != me)
+  ok &= (first[cand] == last).all(dim=1)
+  ok &= (last >= 0).all(dim=1)
+  succ = torch.where(ok, cand, torch.full_like(cand, -1))
+  # a face has two elements, so successors are distinct; keep it true anyway
+  pred = torch.full((m,), -1, dtype=torch.int64, device=dev)
+  src = torch.nonzero(succ >= 0).reshape(-1)
+  pred[succ[src]] = src
+  valid = torch.zeros(m, dtype=torch.bool, device=dev)
+  valid[src] = pred[succ[src]] == src
+  succ = torch.where(valid, succ, torch.full_like(succ, -1))
+  pred.fill_(-1)
+  src = torch.nonzero(succ >= 0).reshape(-1)
+  pred[succ[src]] = src
+  # list ranking by pointer jumping: head and distance to it
+  p = torch.where(pred >= 0, pred, me)
+  d = (pred >= 0).to(torch.int64)
+  for _ in range(max(1, int(m).bit_length())):
+    d = d + d[p]
+    p = p[p]
+  loop = pred[p] >= 0            # closed rings never reach a head
+  if bool(loop.any()):           # members of a ring walk alone
+    p = torch.where(loop, me, p)
+    d = torch.where(loop, torch.zeros_like(d), d)
+  key = p * (int(d.max()) + 1 if m else 1) + d
+  walk = torch.argsort(key)
+  rank = d[walk]
+  starts = torch.nonzero(rank % seg_len == 0).reshape(-1)
+  offsets = torch.cat([starts, torch.tensor([m], device=dev)])
+  return (offsets.to(torch.int32).contiguous(),
+          ids[walk].to(torch.int32).contiguous())
+
+
 def _facet_parts(fespace, parts, mask, multiplicity, coef):
   """`parts` re-expressed on compact connectivity (`sfem_facet_table_build`):
   elements whose index row is 27 affine facet maps (every `refine_premesh`
@@ -112,6 +166,8 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
   every = torch.arange(E, device=ok.device)
   cst = None
   out = []
+  P = mesh.gridpoints_1d.num_points
+  seg_len = int(os.environ.get('SFEM_CHAIN_LEN', '8'))
 
   def add(part, ids, mode, facet):
     if ids.numel() == 0:
@@ -124,6 +180,12 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
       new.pop('shared_order', None)
       new['facet_table'] = tab
       new['geo_const'] = cst
+      # chains pay where the element arithmetic is light (box / affine:
+      # 0.72 -> 0.58 / 0.66 ms at config 2); the multilinear and stored-factor
+      # kernels have no registers left for the look-ahead (measured slower)
+      if seg_len > 1 and mode in (_GEO_BOX, _GEO_AFFINE):
+        new['chains'] = facet_chains(mesh.elements, ids, P, seg_len)
+        new['chain_len'] = seg_len
     out.append(new)
 
   use_box = os.environ.get('SFEM_BOX', '1') != '0'
@@ -332,7 +394,12 @@ class HelmholtzOperator:
         else:
           lst = torch.nonzero(keep).reshape(-1).to(torch.int32)
         if lst.numel():
-          parts.append(dict(part, elem_list=lst.contiguous()))
+          new = dict(part, elem_list=lst.contiguous())
+          if 'chains' in new:
+            new['chains'] = facet_chains(
+                self.fespace.mesh.elements, lst.to(torch.int64),
+                self.fespace.mesh.gridpoints_1d.num_points, new['chain_len'])
+          parts.append(new)
       return parts
 
     halves = []
@@ -389,6 +456,37 @@ class HelmholtzOperator:
     """`u -> apply(u, lambda0, lambda1)` as an object that `cg` recognises:
     it also offers `apply_with_dot(u, partials)` (fused p.Ap)."""
     return FusedLinearOperator(self, lambda0, lambda1)
+
+  def bytes_per_apply(self, lambda0=0.0, ncomp=1):
+    """Bytes one `apply` HAS to move, launch by launch (what the roofline of
+    bench.py divides by): the field in and out once (`2 s N ncomp`), the
+    connectivity each launch reads -- 432 bytes per element from a facet
+    table (+ 4 per element of a chain list), or `4 n` per element of index
+    rows plus `2 S` of sorted shared slots -- and the geometry it reads: 64
+    bytes (affine / box constants) or `24 s` (multilinear coefficients) per
+    element, `(6 or 7) s n` for elements with stored factors."""
+    mesh = self.fespace.mesh
+    E, n = mesh.elements.shape
+    s = 8 if self.fespace.dtype == torch.float64 else 4
+    total = 2 * s * mesh.num_nodes * ncomp
+    parts = self.facet_parts if self.facet_parts is not None else self.parts
+    for part in parts:
+      count = part['elem_list'].numel() if 'elem_list' in part else E
+      mode = part['geo_mode']
+      if 'facet_table' in part:
+        conn = 27 * 16 + (4 if 'chains' in part and ncomp == 1 else 0)
+      else:
+        conn = 4 * n + (4 if 'elem_list' in part else 0)
+        if part.get('shared_order') is not None:
+          conn += 2 * part['shared_order'].shape[1]
+      if mode == _GEO_POINT:
+        geo = (7 if lambda0 else 6) * s * n
+      elif 'facet_table' in part and mode in (_GEO_AFFINE, _GEO_BOX):
+        geo = 8 * s
+      else:
+        geo = 24 * s
+      total += count * (conn + geo)
+    return total
 
   def kernel_name(self, lambda0=0.0, lambda1=1.0, ncomp=1):
     """Name(s) of the kernel instantiation(s) `apply` launches, as they appear

@@ -241,6 +241,9 @@ struct HelmholtzCall {
   const int32_t* facet_table = nullptr;
   const void* geo_const = nullptr;
   int64_t num_nodes = 0;
+  const int32_t* chain_offsets = nullptr;
+  const int32_t* chain_elems = nullptr;
+  int64_t num_chains = 0;
 };
 
 template <typename T>
@@ -272,7 +275,11 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
     fp.elem_list = prm.elem_list; fp.comp_stride = prm.comp_stride;
     fp.ncomp = prm.ncomp; fp.lambda0 = prm.lambda0; fp.lambda1 = prm.lambda1;
     fp.dot_out = prm.dot_out;
-    return dispatch_helmholtz_facet<T>(fp, c.P, c.geo_mode, c.num_elements,
+    fp.chain_off = c.chain_offsets;
+    fp.chain_elems = c.chain_elems;
+    return dispatch_helmholtz_facet<T>(fp, c.P, c.geo_mode,
+                                       c.chain_offsets ? c.num_chains
+                                                       : c.num_elements,
                                        c.num_nodes, prm.dmat_host,
                                        prm.weights_host, prm.nodes_host,
                                        stream);
@@ -438,6 +445,14 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
     c.facet_table = a->facet_table;
     c.geo_const = a->geo_const;
     c.num_nodes = a->num_nodes;
+    if (a->chain_offsets) {
+      SFEM_REQUIRE(a->chain_elems && a->num_chains > 0 && a->ncomp == 1,
+                   "sfem_helmholtz_apply: chains need chain_elems, "
+                   "num_chains > 0 and a scalar field");
+      c.chain_offsets = a->chain_offsets;
+      c.chain_elems = a->chain_elems;
+      c.num_chains = a->num_chains;
+    }
   }
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));

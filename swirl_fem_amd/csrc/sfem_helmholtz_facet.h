@@ -59,6 +59,8 @@ struct FacetParams {
   const T* geo;              // per-point factors (GEO_POINT)
   const int32_t* geo_index;  // (E,) slot in `geo` or null
   const int32_t* elem_list;  // ids of the elements of this launch, or null
+  const int32_t* chain_off;   // chain launches: (S + 1,) segment bounds in
+  const int32_t* chain_elems; //   chain_elems (element ids in walking order)
   int64_t comp_stride;       // component k of node n at u[n + k comp_stride]
   int ncomp;
   T lambda0, lambda1;
@@ -217,24 +219,33 @@ __device__ __forceinline__ T* facet_node(T* base, uint32_t code) {
 // the INNER facet.  Flags ride in the two top bits of t[].
 template <int P>
 struct FacetLane {
+  typedef int32_t I4 __attribute__((ext_vector_type(4)));
+  struct Raw { I4 en[3]; };   // the lane's three table entries as loaded
   uint32_t t[3];
   int32_t sa;
   static __device__ __forceinline__ int cls(int a) {
     return a == 0 ? 0 : (a == P - 1 ? 2 : 1);
   }
-  __device__ __forceinline__ void load(const int32_t* tab, int64_t e, int i,
-                                       int j) {
-    typedef int32_t I4 __attribute__((ext_vector_type(4)));
+  // requests the entries (3 x 16 bytes per lane); no wait
+  static __device__ __forceinline__ void issue(Raw& raw, const int32_t* tab,
+                                               int64_t e, int i, int j) {
     const int lc = cls(i) * 3 + cls(j);
     const I4* row = reinterpret_cast<const I4*>(tab + e * FACET_ROW);
-    I4 en[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) en[c] = row[c * 9 + lc];
+    for (int c = 0; c < 3; ++c) raw.en[c] = row[c * 9 + lc];
+  }
+  __device__ __forceinline__ void finish(const Raw& raw, int i, int j) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      t[c] = (uint32_t)en[c].x + (uint32_t)__mul24(en[c].z, i - 1) +
-             (uint32_t)__mul24(en[c].w, j - 1);
-    sa = en[1].y;
+      t[c] = (uint32_t)raw.en[c].x + (uint32_t)__mul24(raw.en[c].z, i - 1) +
+             (uint32_t)__mul24(raw.en[c].w, j - 1);
+    sa = raw.en[1].y;
+  }
+  __device__ __forceinline__ void load(const int32_t* tab, int64_t e, int i,
+                                       int j) {
+    Raw raw;
+    issue(raw, tab, e, i, j);
+    finish(raw, i, j);
   }
   // node id | flags of the lane's node in slice a (compile-time a)
   __device__ __forceinline__ uint32_t code(int a) const {
@@ -247,15 +258,14 @@ struct FacetLane {
 };
 
 // Direct-stiffness summation of one element's results `acc` (slot layout:
-// lane (i, j) holds nodes (a, i, j)).  `vals` / `codes`: free LDS of
-// FacetLayout<P>::WORDS words of T resp. uint32.
-template <typename T, int P, bool OFF32>
-__device__ __forceinline__ void facet_scatter(
-    const FacetLane<P>& fl, const uint32_t (&slots)[3], T (&acc)[P],
-    const T (&ua)[P], T* og, T* vals, uint32_t* codes, uint32_t own_w,
-    bool want_dot, double& udot) {
-  using L = FacetLayout<P>;
-  // Dirichlet rows are zero
+// lane (i, j) holds nodes (a, i, j)), in two halves so that a kernel can issue
+// other memory traffic between them.  Head: Dirichlet rows and u . out.
+template <typename T, int P>
+__device__ __forceinline__ void facet_scatter_head(const FacetLane<P>& fl,
+                                                   T (&acc)[P],
+                                                   const T (&ua)[P],
+                                                   bool want_dot,
+                                                   double& udot) {
 #pragma unroll
   for (int a = 0; a < P; ++a)
     if (fl.flags(a) & SFEM_IDX_DIRICHLET) acc[a] = T(0);
@@ -263,7 +273,16 @@ __device__ __forceinline__ void facet_scatter(
 #pragma unroll
     for (int a = 0; a < P; ++a) udot += (double)acc[a] * (double)ua[a];
   }
-  // nodes of this element only: plain stores
+}
+
+// Tail: plain stores for the nodes of this element only, atomics for the
+// shared ones.  `vals` / `codes`: free LDS of FacetLayout<P>::WORDS words of T
+// resp. uint32.
+template <typename T, int P, bool OFF32>
+__device__ __forceinline__ void facet_scatter_tail(
+    const FacetLane<P>& fl, const uint32_t (&slots)[3], const T (&acc)[P],
+    T* og, T* vals, uint32_t* codes, uint32_t own_w) {
+  using L = FacetLayout<P>;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     if (!(fl.t[c] & SFEM_IDX_SHARED)) {
@@ -290,20 +309,31 @@ __device__ __forceinline__ void facet_scatter(
     const uint32_t w = (slots[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
     if (w != 0xFFFFu) {
       const uint32_t code = codes[w];
+#if SFEM_FACET_TIMING == 7        // timing only: no edge / vertex atomics
+      if ((threadIdx.x & 63) >= (P - 2) * (P - 2)) continue;
+#elif SFEM_FACET_TIMING == 8      // timing only: no face atomics
+      if ((threadIdx.x & 63) < (P - 2) * (P - 2)) continue;
+#endif
       if ((code & ~(uint32_t)SFEM_IDX_MASK) == SFEM_IDX_SHARED) {
-#if SFEM_FACET_TIMING == 3 || SFEM_FACET_TIMING == 6     // timing experiments only (wrong sums)
+#if SFEM_FACET_TIMING == 3 || SFEM_FACET_TIMING == 6     // timing only
         asm volatile("" :: "v"(vals[w]), "v"(code));
 #elif SFEM_FACET_TIMING == 1
         *facet_node<T, OFF32>(og, code) = vals[w];
-#elif SFEM_FACET_TIMING == 2
-        T* dst = facet_node<T, OFF32>(og, code);
-        *dst = *dst + vals[w];
 #else
         unsafeAtomicAdd(facet_node<T, OFF32>(og, code), vals[w]);
 #endif
       }
     }
   }
+}
+
+template <typename T, int P, bool OFF32>
+__device__ __forceinline__ void facet_scatter(
+    const FacetLane<P>& fl, const uint32_t (&slots)[3], T (&acc)[P],
+    const T (&ua)[P], T* og, T* vals, uint32_t* codes, uint32_t own_w,
+    bool want_dot, double& udot) {
+  facet_scatter_head<T, P>(fl, acc, ua, want_dot, udot);
+  facet_scatter_tail<T, P, OFF32>(fl, slots, acc, og, vals, codes, own_w);
 }
 
 // Kernel-argument offsets (the matrices and the slot table are read through
@@ -326,37 +356,23 @@ __device__ __forceinline__ const char* kernarg_bytes() {
 #endif
 }
 
-template <int P>
-struct FacetWave {
-  static constexpr int TPE = P * P;
-  static constexpr int LDS_WORDS = 2 * FacetLayout<P>::COPY;
-};
-
 #ifndef SFEM_FACET_TIMING
 #define SFEM_FACET_TIMING 0
 #endif
 #ifndef SFEM_FACET_XCD
 #define SFEM_FACET_XCD 0
 #endif
-// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2):
-// blocks b and b + 8 share one.  The remap hands every XCD a contiguous run of
-// the element list, so that elements that share faces (neighbours in the
-// list) meet in one L2.
-__device__ __forceinline__ uint32_t facet_work_item() {
-#if SFEM_FACET_XCD
-  const uint32_t b = blockIdx.x, g = gridDim.x;
-  const uint32_t chunk = g >> 3, rem = g & 7;     // XCD x takes chunk (+1 if x < rem)
-  const uint32_t x = b & 7, s = b >> 3;
-  return x * chunk + (x < rem ? x : rem) + s;
-#else
-  return blockIdx.x;
-#endif
-}
 #ifndef SFEM_FACET_AFFINE_MINW
 #define SFEM_FACET_AFFINE_MINW 5
 #endif
 #ifndef SFEM_FACET_BOX_MINW
 #define SFEM_FACET_BOX_MINW 5
+#endif
+#ifndef SFEM_FACET_CHAIN_MINW_BOX
+#define SFEM_FACET_CHAIN_MINW_BOX 4
+#endif
+#ifndef SFEM_FACET_CHAIN_MINW_AFFINE
+#define SFEM_FACET_CHAIN_MINW_AFFINE 4
 #endif
 
 // 1D quadrature weight of slice a; the node sets are symmetric (supports_fused),
@@ -366,74 +382,86 @@ __device__ __forceinline__ T sym_w(const M& m, int a) {
   return m.w[a < P - 1 - a ? a : P - 1 - a];
 }
 
-// General geometry: GM = GEO_POINT / GEO_AFFINE / GEO_MULTILINEAR.
-template <typename T, int P, int GM, bool MASS, bool SCALAR, bool OFF32>
-__global__ void __launch_bounds__(
-    64, (GM == GEO_AFFINE ? SFEM_FACET_AFFINE_MINW : 4))
-helmholtz_facet_kernel(FacetParams<T> prm, DMat<T, P> dm, FacetSlots st) {
+// Lane constants of a one-wave element.
+template <int P>
+struct FacetWave {
   using L = FacetLayout<P>;
-  using KA = FacetKernarg<FacetParams<T>, DMat<T, P>>;
-  constexpr int TPE = P * P;
-  __shared__ T lds[2 * L::COPY];
-  T* s0 = lds;
-  T* s1 = lds + L::COPY;
+  static constexpr int TPE = P * P;
+  int lane, i, j;
+  bool ok;                          // lane holds a line of the element
+  uint32_t own_w, mid_w, last_w;    // LDS words of the three access patterns
+  template <typename T, typename M>
+  __device__ __forceinline__ T wij(const M* kmat) const {
+    return kmat->w[i] * kmat->w[j];
+  }
+  __device__ __forceinline__ void init() {
+    lane = threadIdx.x;
+    ok = TPE == 64 || lane < TPE;
+    const int t = ok ? lane : 0;
+    i = t / P;
+    j = t - i * P;
+    own_w = L::B * i + j;
+    mid_w = L::SWAP ? L::A * j + i : L::A * i + j;
+    last_w = L::SWAP ? L::A * j + L::B * i : L::A * i + L::B * j;
+  }
+};
 
-  const int lane = threadIdx.x;
-  const bool lane_ok = TPE == 64 || lane < TPE;
-  const int t = lane_ok ? lane : 0;
-  const int i = t / P, j = t - i * P;
-  const uint32_t work = facet_work_item();
-  const int64_t e = prm.elem_list ? (int64_t)prm.elem_list[work]
-                                  : (int64_t)work;
-  const DMat<T, P>* kdm =
-      reinterpret_cast<const DMat<T, P>*>(kernarg_bytes() + KA::MAT_OFF);
-  const FacetSlots* kst =
-      reinterpret_cast<const FacetSlots*>(kernarg_bytes() + KA::SLOT_OFF);
-
-  FacetLane<P> fl;
-  fl.load(prm.tab, e, i, j);
-
-  // LDS words of the lane's three access patterns
-  const uint32_t own_w = L::B * i + j;
-  const uint32_t mid_w = L::SWAP ? L::A * j + i : L::A * i + j;
-  const uint32_t last_w = L::SWAP ? L::A * j + L::B * i : L::A * i + L::B * j;
-
-  // geometry
-  const T* cst = prm.geo_const + e * 8;          // affine: wave-uniform
-  T lw = T(0), Wm0 = T(0);
+// (lambda0 B + lambda1 A)_local of one element, general geometry
+// (GM = GEO_POINT / GEO_AFFINE / GEO_MULTILINEAR); two LDS copies.
+template <typename T, int P, int GM, bool MASS>
+struct FacetElem {
+  using L = FacetLayout<P>;
+  using Mat = DMat<T, P>;
+  static constexpr int LDS_WORDS = 2 * L::COPY;
+  static constexpr int MINW = GM == GEO_AFFINE ? SFEM_FACET_AFFINE_MINW : 4;
+  static constexpr int CHAIN_MINW =
+      GM == GEO_AFFINE ? SFEM_FACET_CHAIN_MINW_AFFINE : 4;
+  struct Raw { T c[GM == GEO_AFFINE ? 7 : 1]; int64_t e; };
+  T cst[GM == GEO_AFFINE ? 6 : 1];
+  T lw, Wm0;
   ElemGeom<T, P, 3, (GM == GEO_AFFINE ? GEO_POINT : GM)> geom;
-  if constexpr (GM == GEO_AFFINE) {
-    const T wij = kdm->w[i] * kdm->w[j];
-    lw = prm.lambda1 * wij;
-    if (MASS) Wm0 = prm.lambda0 * cst[6] * wij;
-  } else {
-    HelmholtzParams<T> hp{};
-    hp.geo = prm.geo;
-    hp.geo_elem = prm.geo_elem;
-    hp.geo_index = prm.geo_index;
-    geom.template init<true>(hp, dm, e, true, i, j, t, kdm);
+
+  // requests the element's constants (wave-uniform addresses); no wait
+  static __device__ __forceinline__ void fetch(Raw& raw,
+                                               const FacetParams<T>& prm,
+                                               int64_t e) {
+    raw.e = e;
+    if constexpr (GM == GEO_AFFINE) {
+      const T* g = prm.geo_const + e * 8;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) raw.c[q] = g[q];
+    }
+  }
+  __device__ __forceinline__ void finish(const Raw& raw,
+                                         const FacetParams<T>& prm,
+                                         const Mat& dm, const Mat* kdm,
+                                         const FacetWave<P>& w, T wij) {
+    lw = T(0);
+    Wm0 = T(0);
+    if constexpr (GM == GEO_AFFINE) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) cst[q] = raw.c[q];
+      lw = prm.lambda1 * wij;
+      if (MASS) Wm0 = prm.lambda0 * raw.c[6] * wij;
+    } else {
+      HelmholtzParams<T> hp{};
+      hp.geo = prm.geo;
+      hp.geo_elem = prm.geo_elem;
+      hp.geo_index = prm.geo_index;
+      geom.template init<true>(hp, dm, raw.e, true, w.i, w.j,
+                               w.ok ? w.lane : 0, kdm);
+    }
   }
 
-  const int nc = SCALAR ? 1 : prm.ncomp;
-  double udot = 0.0;
-  for (int k = 0; k < nc; ++k) {
-    const T* ug = prm.u + (SCALAR ? 0 : k * prm.comp_stride);
-    T* og = prm.out + (SCALAR ? 0 : k * prm.comp_stride);
-    T ua[P], acc[P];
-    if (lane_ok) {
-#pragma unroll
-      for (int a = 0; a < P; ++a)
-#if SFEM_FACET_TIMING == 4 || SFEM_FACET_TIMING == 6
-        ua[a] = (T)fl.code(a);
-#else
-        ua[a] = *facet_node<const T, OFF32>(ug, fl.code(a));
-#endif
-    } else {
-#pragma unroll
-      for (int a = 0; a < P; ++a) ua[a] = T(0);
-    }
-    const bool has_stiff = prm.lambda1 != T(0);
-    if (has_stiff) {
+  __device__ __forceinline__ void apply(const FacetParams<T>& prm,
+                                        const Mat& dm, const FacetWave<P>& w,
+                                        T* lds, const T (&ua)[P],
+                                        T (&acc)[P]) const {
+    T* s0 = lds;
+    T* s1 = lds + L::COPY;
+    const bool lane_ok = w.ok;
+    const uint32_t own_w = w.own_w, mid_w = w.mid_w, last_w = w.last_w;
+    if (prm.lambda1 != T(0)) {
       if (lane_ok) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
@@ -462,9 +490,13 @@ helmholtz_facet_kernel(FacetParams<T> prm, DMat<T, P> dm, FacetSlots st) {
       T w0[P];
       line_apply<T, P, false>(dm, ua, w0);
       wave_sync();
+      if (MASS || !lane_ok) {
 #pragma unroll
-      for (int a = 0; a < P; ++a) acc[a] = T(0);
+        for (int a = 0; a < P; ++a) acc[a] = T(0);
+      }
       if (lane_ok) {
+        T chain = T(0);
+        (void)chain;
 #pragma unroll
         for (int a = 0; a < P; ++a) {
           T& r0 = s0[own_w + a * L::A];
@@ -472,14 +504,29 @@ helmholtz_facet_kernel(FacetParams<T> prm, DMat<T, P> dm, FacetSlots st) {
           if constexpr (GM == GEO_AFFINE) {
             const T g0 = w0[a], g1 = r0, g2 = r1;
             const T wa = sym_w<T, P>(dm, a);
-            const T sc = lw * wa;
+            // (pinned: eight hoisted products would hold 16 registers)
+            T lwa = lw;
+            asm volatile("" : "+v"(lwa));
+            const T sc = lwa * wa;
             w0[a] = sc * (cst[0] * g0 + cst[1] * g1 + cst[2] * g2);
             r0 = sc * (cst[1] * g0 + cst[3] * g1 + cst[4] * g2);
             r1 = sc * (cst[2] * g0 + cst[4] * g1 + cst[5] * g2);
-            if (MASS) acc[a] = (Wm0 * wa) * ua[a];
+            if (MASS) acc[a] = (Wm0 * ua[a]) * wa;
           } else if constexpr (GM == GEO_MULTILINEAR) {
             T o0, o1, o2, Wm;
-            geom.apply_multilinear3(dm, a, MASS, w0[a], r0, r1, o0, o1, o2, Wm);
+            // the factors of a slice do not depend on loaded data: keep the
+            // scheduler from evaluating all eight ahead of the passes above
+            // (160 more live registers, measured 218 VGPRs instead of 126)
+            T g0 = w0[a];
+            ElemGeom<T, P, 3, GM> gs = geom;
+            // ... and the slices one after the other (each waits for the
+            // previous slice's result `chain`)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              asm volatile("" : "+v"(gs.p1[c]), "+v"(gs.p2[c]), "+v"(g0)
+                           : "v"(chain));
+            gs.apply_multilinear3(dm, a, MASS, g0, r0, r1, o0, o1, o2, Wm);
+            chain = o2;
             if (MASS) acc[a] = prm.lambda0 * Wm * ua[a];
             w0[a] = o0; r0 = o1; r1 = o2;
           } else {
@@ -497,8 +544,10 @@ helmholtz_facet_kernel(FacetParams<T> prm, DMat<T, P> dm, FacetSlots st) {
         line_apply<T, P, true>(dm, w0, dt0);
 #pragma unroll
         for (int a = 0; a < P; ++a) {
-          if (GM == GEO_AFFINE) acc[a] += dt0[a];    // lambda1 is inside lw
-          else acc[a] += prm.lambda1 * dt0[a];
+          // lambda1 is inside lw for affine elements
+          const T v = GM == GEO_AFFINE ? dt0[a] : prm.lambda1 * dt0[a];
+          if (MASS || !lane_ok) acc[a] += v;
+          else acc[a] = v;
         }
       }
       wave_sync();
@@ -552,84 +601,51 @@ helmholtz_facet_kernel(FacetParams<T> prm, DMat<T, P> dm, FacetSlots st) {
         }
       }
     }
-    if (lane_ok) {
-      uint32_t slots[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) slots[q] = kst->pk[lane][q];
-      facet_scatter<T, P, OFF32>(fl, slots, acc, ua, og, s0,
-                                 reinterpret_cast<uint32_t*>(s1), own_w,
-                                 prm.dot_out != nullptr, udot);
-    }
-    wave_sync();
   }
-  if (prm.dot_out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
-    if (lane == 0)
-      unsafeAtomicAdd(&prm.dot_out[blockIdx.x & (SFEM_DOT_SLOTS - 1)], udot);
-  }
-}
+};
 
 // Box elements: J^-1 J^-T diagonal and constant.  With K = D^T diag(w) D,
 //   A_loc u (a,i,j) = c0 w_i w_j (K u)_a + w_a ( c1 w_j (K u)_i + c2 w_i (K u)_j )
 //   B_loc u = detJ w_a w_i w_j u
-// One LDS copy: both transposed passes read it before either writes back.
-template <typename T, int P, bool MASS, bool SCALAR, bool OFF32>
-__global__ void __launch_bounds__(64, SFEM_FACET_BOX_MINW)
-helmholtz_box_kernel(FacetParams<T> prm, SMat<T, P> sm, FacetSlots st) {
+// One LDS copy (both transposed passes read it before either writes back) plus
+// room for the codes of the shared scatter.
+template <typename T, int P, bool MASS>
+struct BoxElem {
   using L = FacetLayout<P>;
-  using KA = FacetKernarg<FacetParams<T>, SMat<T, P>>;
-  constexpr int TPE = P * P;
-  // one copy of the element and the codes of the shared scatter
-  constexpr int CODE_WORDS = (L::COPY * 4 + (int)sizeof(T) - 1) / (int)sizeof(T);
-  __shared__ T lds[L::COPY + CODE_WORDS];
-  T* s0 = lds;
-  T* s1 = lds + L::COPY;
+  using Mat = SMat<T, P>;
+  static constexpr int CODE_WORDS =
+      (L::COPY * 4 + (int)sizeof(T) - 1) / (int)sizeof(T);
+  static constexpr int LDS_WORDS = L::COPY + CODE_WORDS;
+  static constexpr int MINW = SFEM_FACET_BOX_MINW;
+  static constexpr int CHAIN_MINW = SFEM_FACET_CHAIN_MINW_BOX;
+  struct Raw { T c[4]; };
+  T P0, P1, P2, Wm;
 
-  const int lane = threadIdx.x;
-  const bool lane_ok = TPE == 64 || lane < TPE;
-  const int t = lane_ok ? lane : 0;
-  const int i = t / P, j = t - i * P;
-  const uint32_t work = facet_work_item();
-  const int64_t e = prm.elem_list ? (int64_t)prm.elem_list[work]
-                                  : (int64_t)work;
-  const SMat<T, P>* ksm =
-      reinterpret_cast<const SMat<T, P>*>(kernarg_bytes() + KA::MAT_OFF);
-  const FacetSlots* kst =
-      reinterpret_cast<const FacetSlots*>(kernarg_bytes() + KA::SLOT_OFF);
+  // requests c0, c1, c2, detJ (wave-uniform addresses); no wait
+  static __device__ __forceinline__ void fetch(Raw& raw,
+                                               const FacetParams<T>& prm,
+                                               int64_t e) {
+    const T* g = prm.geo_const + e * 8;
+    raw.c[0] = g[0]; raw.c[1] = g[3]; raw.c[2] = g[5]; raw.c[3] = g[6];
+  }
+  __device__ __forceinline__ void finish(const Raw& raw,
+                                         const FacetParams<T>& prm,
+                                         const Mat& sm, const Mat* ksm,
+                                         const FacetWave<P>& w, T wij) {
+    const T wi = ksm->w[w.i], wj = ksm->w[w.j];
+    P0 = prm.lambda1 * raw.c[0] * wij;
+    P1 = prm.lambda1 * raw.c[1] * wj;
+    P2 = prm.lambda1 * raw.c[2] * wi;
+    Wm = MASS ? prm.lambda0 * raw.c[3] * wij : T(0);
+  }
 
-  FacetLane<P> fl;
-  fl.load(prm.tab, e, i, j);
-
-  const uint32_t own_w = L::B * i + j;
-  const uint32_t mid_w = L::SWAP ? L::A * j + i : L::A * i + j;
-  const uint32_t last_w = L::SWAP ? L::A * j + L::B * i : L::A * i + L::B * j;
-
-  const T* cst = prm.geo_const + e * 8;
-  const T wi = ksm->w[i], wj = ksm->w[j];
-  const T P0 = prm.lambda1 * cst[0] * (wi * wj);
-  const T P1 = prm.lambda1 * cst[3] * wj;
-  const T P2 = prm.lambda1 * cst[5] * wi;
-  const T Wm = MASS ? prm.lambda0 * cst[6] * (wi * wj) : T(0);
-
-  const int nc = SCALAR ? 1 : prm.ncomp;
-  double udot = 0.0;
-  for (int k = 0; k < nc; ++k) {
-    const T* ug = prm.u + (SCALAR ? 0 : k * prm.comp_stride);
-    T* og = prm.out + (SCALAR ? 0 : k * prm.comp_stride);
-    T ua[P], acc[P];
-    if (lane_ok) {
-#pragma unroll
-      for (int a = 0; a < P; ++a)
-#if SFEM_FACET_TIMING == 4 || SFEM_FACET_TIMING == 6
-        ua[a] = (T)fl.code(a);
-#else
-        ua[a] = *facet_node<const T, OFF32>(ug, fl.code(a));
-#endif
-    } else {
-#pragma unroll
-      for (int a = 0; a < P; ++a) ua[a] = T(0);
-    }
+  __device__ __forceinline__ void apply(const FacetParams<T>& prm,
+                                        const Mat& sm, const FacetWave<P>& w,
+                                        T* lds, const T (&ua)[P],
+                                        T (&acc)[P]) const {
+    T* s0 = lds;
+    const bool lane_ok = w.ok;
+    const uint32_t own_w = w.own_w, mid_w = w.mid_w, last_w = w.last_w;
     if (prm.lambda1 != T(0)) {
       if (lane_ok) {
 #pragma unroll
@@ -641,7 +657,7 @@ helmholtz_box_kernel(FacetParams<T> prm, SMat<T, P> sm, FacetSlots st) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
           acc[a] = P0 * r0[a];
-          if (MASS) acc[a] += (Wm * sym_w<T, P>(sm, a)) * ua[a];
+          if (MASS) acc[a] += (Wm * ua[a]) * sym_w<T, P>(sm, a);
         }
       }
       wave_sync();
@@ -665,7 +681,7 @@ helmholtz_box_kernel(FacetParams<T> prm, SMat<T, P> sm, FacetSlots st) {
 #pragma unroll
       for (int a = 0; a < P; ++a) {
         const T t2 = lane_ok ? s0[own_w + a * L::A] : T(0);
-        acc[a] += (P2 * sym_w<T, P>(sm, a)) * t2;
+        acc[a] += (P2 * t2) * sym_w<T, P>(sm, a);
       }
       wave_sync();
       if (lane_ok) {
@@ -676,7 +692,7 @@ helmholtz_box_kernel(FacetParams<T> prm, SMat<T, P> sm, FacetSlots st) {
 #pragma unroll
       for (int a = 0; a < P; ++a) {
         const T t1 = lane_ok ? s0[own_w + a * L::A] : T(0);
-        acc[a] += (P1 * sym_w<T, P>(sm, a)) * t1;
+        acc[a] += (P1 * t1) * sym_w<T, P>(sm, a);
       }
       wave_sync();
     } else {
@@ -684,12 +700,64 @@ helmholtz_box_kernel(FacetParams<T> prm, SMat<T, P> sm, FacetSlots st) {
       for (int a = 0; a < P; ++a)
         acc[a] = MASS ? (Wm * sym_w<T, P>(sm, a)) * ua[a] : T(0);
     }
-    if (lane_ok) {
+  }
+};
+
+// One element per one-wave workgroup.  ELEM = FacetElem<..> / BoxElem<..>.
+template <typename T, int P, typename ELEM, bool SCALAR, bool OFF32>
+__global__ void __launch_bounds__(64, ELEM::MINW)
+helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
+                       FacetSlots st) {
+  using L = FacetLayout<P>;
+  using Mat = typename ELEM::Mat;
+  using KA = FacetKernarg<FacetParams<T>, Mat>;
+  __shared__ T lds[ELEM::LDS_WORDS];
+  T* s0 = lds;
+  uint32_t* codes = reinterpret_cast<uint32_t*>(lds + L::COPY);
+
+  FacetWave<P> w;
+  w.init();
+  const uint32_t work = blockIdx.x;
+  const int64_t e = prm.elem_list ? (int64_t)prm.elem_list[work]
+                                  : (int64_t)work;
+  const Mat* kdm = reinterpret_cast<const Mat*>(kernarg_bytes() + KA::MAT_OFF);
+  const FacetSlots* kst =
+      reinterpret_cast<const FacetSlots*>(kernarg_bytes() + KA::SLOT_OFF);
+
+  FacetLane<P> fl;
+  fl.load(prm.tab, e, w.i, w.j);
+  ELEM el;
+  {
+    typename ELEM::Raw raw;
+    ELEM::fetch(raw, prm, e);
+    el.finish(raw, prm, dm, kdm, w, w.template wij<T>(kdm));
+  }
+
+  const int nc = SCALAR ? 1 : prm.ncomp;
+  double udot = 0.0;
+  for (int k = 0; k < nc; ++k) {
+    const T* ug = prm.u + (SCALAR ? 0 : k * prm.comp_stride);
+    T* og = prm.out + (SCALAR ? 0 : k * prm.comp_stride);
+    T ua[P], acc[P];
+    if (w.ok) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+#if SFEM_FACET_TIMING == 4 || SFEM_FACET_TIMING == 6
+        ua[a] = (T)fl.code(a);
+#else
+        ua[a] = *facet_node<const T, OFF32>(ug, fl.code(a));
+#endif
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < P; ++a) ua[a] = T(0);
+    }
+    el.apply(prm, dm, w, lds, ua, acc);
+    if (w.ok) {
       uint32_t slots[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) slots[q] = kst->pk[lane][q];
-      facet_scatter<T, P, OFF32>(fl, slots, acc, ua, og, s0,
-                                 reinterpret_cast<uint32_t*>(s1), own_w,
+      for (int q = 0; q < 3; ++q) slots[q] = kst->pk[w.lane][q];
+      facet_scatter<T, P, OFF32>(fl, slots, acc, ua, og, s0, codes, w.own_w,
                                  prm.dot_out != nullptr, udot);
     }
     wave_sync();
@@ -697,76 +765,190 @@ helmholtz_box_kernel(FacetParams<T> prm, SMat<T, P> sm, FacetSlots st) {
   if (prm.dot_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
-    if (lane == 0)
+    if (w.lane == 0)
+      unsafeAtomicAdd(&prm.dot_out[blockIdx.x & (SFEM_DOT_SLOTS - 1)], udot);
+  }
+}
+
+// One CHAIN SEGMENT per one-wave workgroup: elements order[k0 .. k1) such that
+// the face a = P-1 of each is the face a = 0 of the next, node for node in the
+// lane layout (`sfem_facet_chains`).  The wave walks the segment:
+//   * the shared face travels in registers: its nodal values are gathered
+//     once, its two contributions are added before they leave the wave -- the
+//     face interior is then complete (a face has two elements) and is stored
+//     without an atomic, its edges / vertices take one atomic instead of two;
+//   * the next element's table is requested together with this element's
+//     gather and its gather is issued before this element's scatter, so the
+//     dependent memory round trips of an element overlap with the previous
+//     element's work instead of adding up.  (Gathering a whole element ahead
+//     -- 34 more live registers -- measured 0.569 vs 0.580 ms at 3 waves per
+//     SIMD and 0.655 with spills at 4: not kept.)
+template <typename T, int P, typename ELEM, bool OFF32>
+__global__ void __launch_bounds__(64, ELEM::CHAIN_MINW)
+helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
+                       FacetSlots st) {
+  using L = FacetLayout<P>;
+  using Mat = typename ELEM::Mat;
+  using KA = FacetKernarg<FacetParams<T>, Mat>;
+  __shared__ T lds[ELEM::LDS_WORDS];
+  T* s0 = lds;
+  uint32_t* codes = reinterpret_cast<uint32_t*>(lds + L::COPY);
+
+  FacetWave<P> w;
+  w.init();
+#if SFEM_FACET_XCD
+  // blocks b, b + 8, ... share an XCD (and its L2): give each XCD a
+  // contiguous run of the segment list
+  const uint32_t nseg = gridDim.x, chunk = nseg >> 3, rem = nseg & 7;
+  const uint32_t xcd = blockIdx.x & 7;
+  const uint32_t seg = xcd * chunk + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+#else
+  const uint32_t seg = blockIdx.x;
+#endif
+  const int32_t k0 = prm.chain_off[seg];
+  const int32_t k1 = prm.chain_off[seg + 1];
+  const Mat* kdm = reinterpret_cast<const Mat*>(kernarg_bytes() + KA::MAT_OFF);
+  const FacetSlots* kst =
+      reinterpret_cast<const FacetSlots*>(kernarg_bytes() + KA::SLOT_OFF);
+  uint32_t slots[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) slots[q] = kst->pk[w.lane][q];
+  const bool face_inner = FacetLane<P>::cls(w.i) == 1 &&
+                          FacetLane<P>::cls(w.j) == 1;
+  const T* ug = prm.u;
+  T* og = prm.out;
+
+  const T wij = w.template wij<T>(kdm);
+  double udot = 0.0;
+  T carry = T(0);
+  {
+  FacetLane<P> fl, fn;
+  typename FacetLane<P>::Raw traw;
+  typename ELEM::Raw graw;
+  fl.load(prm.tab, (int64_t)prm.chain_elems[k0], w.i, w.j);
+  fn = fl;
+  ELEM::fetch(graw, prm, (int64_t)prm.chain_elems[k0]);
+  T ua[P];
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+    ua[a] = w.ok ? *facet_node<const T, OFF32>(ug, fl.code(a)) : T(0);
+  if (k0 + 1 < k1)
+    FacetLane<P>::issue(traw, prm.tab, (int64_t)prm.chain_elems[k0 + 1], w.i,
+                        w.j);
+  for (int32_t k = k0; k < k1; ++k) {
+    const bool has_pred = k > k0, has_succ = k + 1 < k1;
+    ELEM el;
+    el.finish(graw, prm, dm, kdm, w, wij);
+    if (has_succ) {    // requested one element ago: arrives with the gather
+      fn.finish(traw, w.i, w.j);
+      ELEM::fetch(graw, prm, (int64_t)prm.chain_elems[k + 1]);
+    }
+    T acc[P];
+    el.apply(prm, dm, w, lds, ua, acc);
+    if (has_pred) acc[0] += carry;
+    carry = acc[P - 1];
+    // flags of this visit: the carried-in face interior is complete, the
+    // carried-out face is left to the successor
+    FacetLane<P> fe = fl;
+    if (has_pred && face_inner) fe.t[0] &= ~(uint32_t)SFEM_IDX_SHARED;
+    if (has_succ) fe.t[2] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
+    const T u_last = ua[P - 1];
+    if (w.ok)
+      facet_scatter_head<T, P>(fe, acc, ua, prm.dot_out != nullptr, udot);
+    // next element: gather now, its successor's table with it
+    fl = fn;
+    if (has_succ) {
+      ua[0] = u_last;
+#pragma unroll
+      for (int a = 1; a < P; ++a)
+        ua[a] = w.ok ? *facet_node<const T, OFF32>(ug, fl.code(a)) : T(0);
+      if (k + 2 < k1)
+        FacetLane<P>::issue(traw, prm.tab, (int64_t)prm.chain_elems[k + 2],
+                            w.i, w.j);
+    }
+    if (w.ok)
+      facet_scatter_tail<T, P, OFF32>(fe, slots, acc, og, s0, codes, w.own_w);
+    wave_sync();
+  }
+  }
+  if (prm.dot_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
+    if (w.lane == 0)
       unsafeAtomicAdd(&prm.dot_out[blockIdx.x & (SFEM_DOT_SLOTS - 1)], udot);
   }
 }
 
 // ----------------------------------------------------------------- launch ---
+template <typename T, int P, typename ELEM>
+void launch_facet_elem(const FacetParams<T>& prm, const typename ELEM::Mat& mat,
+                       const FacetSlots& slots, unsigned groups, bool off32,
+                       hipStream_t stream) {
+  const dim3 grid(groups), block(64);
+  if (prm.chain_off) {
+    if (off32)
+      hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, true>), grid,
+                         block, 0, stream, prm, mat, slots);
+    else
+      hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, false>), grid,
+                         block, 0, stream, prm, mat, slots);
+  } else if (prm.ncomp == 1) {
+    if (off32)
+      hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, true, true>),
+                         grid, block, 0, stream, prm, mat, slots);
+    else
+      hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, true, false>),
+                         grid, block, 0, stream, prm, mat, slots);
+  } else {
+    if (off32)
+      hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, false, true>),
+                         grid, block, 0, stream, prm, mat, slots);
+    else
+      hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, false, false>),
+                         grid, block, 0, stream, prm, mat, slots);
+  }
+}
+
+// `groups`: workgroups of the launch = elements, or chain segments when
+// prm.chain_off is set (scalar fields only).
 template <typename T, int P>
 int launch_helmholtz_facet(const FacetParams<T>& prm, int geo_mode,
-                           int64_t num_elements, int64_t field_reals,
+                           int64_t groups, int64_t field_reals,
                            const T* dmat, const T* weights, const T* nodes,
                            hipStream_t stream) {
-  if (num_elements > 0x7fffffff) {
+  if (groups > 0x7fffffff) {
     set_error("helmholtz (facet): too many workgroups (%lld)",
-              (long long)num_elements);
+              (long long)groups);
+    return SFEM_EINVAL;
+  }
+  if (prm.chain_off && prm.ncomp != 1) {
+    set_error("helmholtz (facet): chain launches take scalar fields");
     return SFEM_EINVAL;
   }
   static const FacetSlots slots = make_facet_slots<P>();
-  const dim3 grid((unsigned)num_elements), block(64);
+  const unsigned g = (unsigned)groups;
   const bool mass = prm.lambda0 != T(0);
-  const bool scalar = prm.ncomp == 1;
   const bool off32 = (uint64_t)field_reals * sizeof(T) < ((uint64_t)1 << 32);
-#define SFEM_FACET_GO(KERNEL, MAT)                                            \
-  do {                                                                        \
-    if (mass) {                                                               \
-      if (scalar) {                                                           \
-        if (off32) hipLaunchKernelGGL((KERNEL(true, true, true)), grid,       \
-                                      block, 0, stream, prm, MAT, slots);     \
-        else hipLaunchKernelGGL((KERNEL(true, true, false)), grid, block, 0,  \
-                                stream, prm, MAT, slots);                     \
-      } else {                                                                \
-        if (off32) hipLaunchKernelGGL((KERNEL(true, false, true)), grid,      \
-                                      block, 0, stream, prm, MAT, slots);     \
-        else hipLaunchKernelGGL((KERNEL(true, false, false)), grid, block, 0, \
-                                stream, prm, MAT, slots);                     \
-      }                                                                       \
-    } else {                                                                  \
-      if (scalar) {                                                           \
-        if (off32) hipLaunchKernelGGL((KERNEL(false, true, true)), grid,      \
-                                      block, 0, stream, prm, MAT, slots);     \
-        else hipLaunchKernelGGL((KERNEL(false, true, false)), grid, block, 0, \
-                                stream, prm, MAT, slots);                     \
-      } else {                                                                \
-        if (off32) hipLaunchKernelGGL((KERNEL(false, false, true)), grid,     \
-                                      block, 0, stream, prm, MAT, slots);     \
-        else hipLaunchKernelGGL((KERNEL(false, false, false)), grid, block,   \
-                                0, stream, prm, MAT, slots);                  \
-      }                                                                       \
-    }                                                                         \
-  } while (0)
-#define SFEM_FACET_BOX(M, S, O) helmholtz_box_kernel<T, P, M, S, O>
-#define SFEM_FACET_AFF(M, S, O) \
-  helmholtz_facet_kernel<T, P, GEO_AFFINE, M, S, O>
-#define SFEM_FACET_MUL(M, S, O) \
-  helmholtz_facet_kernel<T, P, GEO_MULTILINEAR, M, S, O>
-#define SFEM_FACET_PNT(M, S, O) \
-  helmholtz_facet_kernel<T, P, GEO_POINT, M, S, O>
   if (geo_mode == GEO_BOX) {
     const SMat<T, P> sm = make_smat<T, P>(dmat, weights);
-    SFEM_FACET_GO(SFEM_FACET_BOX, sm);
+    if (mass) launch_facet_elem<T, P, BoxElem<T, P, true>>(prm, sm, slots, g,
+                                                           off32, stream);
+    else launch_facet_elem<T, P, BoxElem<T, P, false>>(prm, sm, slots, g,
+                                                       off32, stream);
   } else {
     const DMat<T, P> dm = make_dmat<T, P>(dmat, weights, nodes);
-    if (geo_mode == GEO_AFFINE) SFEM_FACET_GO(SFEM_FACET_AFF, dm);
-    else if (geo_mode == GEO_MULTILINEAR) SFEM_FACET_GO(SFEM_FACET_MUL, dm);
-    else SFEM_FACET_GO(SFEM_FACET_PNT, dm);
+#define SFEM_FACET_GM(GMV)                                                    \
+  do {                                                                        \
+    if (mass) launch_facet_elem<T, P, FacetElem<T, P, GMV, true>>(            \
+        prm, dm, slots, g, off32, stream);                                    \
+    else launch_facet_elem<T, P, FacetElem<T, P, GMV, false>>(                \
+        prm, dm, slots, g, off32, stream);                                    \
+  } while (0)
+    if (geo_mode == GEO_AFFINE) SFEM_FACET_GM(GEO_AFFINE);
+    else if (geo_mode == GEO_MULTILINEAR) SFEM_FACET_GM(GEO_MULTILINEAR);
+    else SFEM_FACET_GM(GEO_POINT);
+#undef SFEM_FACET_GM
   }
-#undef SFEM_FACET_GO
-#undef SFEM_FACET_BOX
-#undef SFEM_FACET_AFF
-#undef SFEM_FACET_MUL
-#undef SFEM_FACET_PNT
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

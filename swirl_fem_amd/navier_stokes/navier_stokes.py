@@ -54,26 +54,45 @@ from swirl_fem_amd import _ops
 # pylint: disable=invalid-name
 
 
+def _uniform_lagrange(k: int, at, derivative: bool) -> np.ndarray:
+  """Values (or first derivatives) at `at` of the k + 1 Lagrange polynomials
+  on the unit-spaced time levels 0, 1, ..., k (oldest first), in exact
+  rational arithmetic."""
+  from fractions import Fraction
+  out = []
+  for j in range(k + 1):
+    others = [m for m in range(k + 1) if m != j]
+    denom = Fraction(1)
+    for m in others:
+      denom *= j - m
+    if not derivative:
+      num = Fraction(1)
+      for m in others:
+        num *= Fraction(at) - m
+    else:               # sum over the factor that is differentiated
+      num = Fraction(0)
+      for skip in others:
+        term = Fraction(1)
+        for m in others:
+          if m != skip:
+            term *= Fraction(at) - m
+        num += term
+    out.append(float(num / denom))
+  return np.array(out, dtype=np.float64)
+
+
 def extk_coeffs(k: int) -> np.ndarray:
-  """Linear extrapolation coefficients of order k."""
-  gridpoints = Nodes1D.create(num_points=k + 1, node_type=NodeType.NEWTON_COTES)
-  h = 2 / k
-  evalpoints = Nodes1D.create_single_point(
-      node_value=np.array(1 + h, dtype=np.float64))
-  interpolator = BarycentricInterpolator(
-      ndim=1, gridpoints_1d=gridpoints, evalpoints_1d=evalpoints)
-  return interpolator.interpolation_matrix().reshape((-1))
+  """Order-k extrapolation to the new time level from the last k + 1 levels,
+  oldest first (reference navier_stokes.py:49-58: Newton-Cotes nodes on
+  [-1, 1] evaluated one step beyond the end)."""
+  return _uniform_lagrange(k, k + 1, derivative=False)
 
 
 def bdfk_coeffs(k: int) -> np.ndarray:
-  """Backward differentiation formula of order k."""
-  gridpoints = Nodes1D.create(num_points=k + 1, node_type=NodeType.NEWTON_COTES)
-  evalpoints = Nodes1D.create_single_point(
-      node_value=np.array(1., dtype=np.float64))
-  interpolator = BarycentricInterpolator(
-      ndim=1, gridpoints_1d=gridpoints, evalpoints_1d=evalpoints)
-  h = 2 / k
-  return interpolator.interpolation_matrix_grad().reshape((-1)) * h
+  """Backward differentiation formula of order k: the derivative at the newest
+  of k + 1 unit-spaced levels, oldest first (reference navier_stokes.py:61-70,
+  whose factor h undoes the [-1, 1] scaling)."""
+  return _uniform_lagrange(k, k, derivative=True)
 
 
 def _solve(differentiable, A, b, **kwargs):

@@ -353,6 +353,22 @@ def test_bench_launches_its_own_ranks():
   assert sum(l.startswith('{') for l in res.stdout.splitlines()) == 1
 
 
+def test_bench_rehearses_the_eight_rank_layout():
+  """`python bench.py --gpus 8 --dry-run`: the 2 x 2 x 2 block grid of the
+  driver's scaling run (7 neighbours per rank: 3 faces, 3 edges, 1 corner),
+  eight gloo ranks on the CPU."""
+  res, line = _run_bench('--gpus', '8', '--backend', 'gloo', '--elems', '2',
+                         '--p', '3', '--dry-run')
+  assert res.returncode == 0, res.stderr[-2000:]
+  assert line['n_gpus'] == 8 and line['config']['world_size_seen'] == 8
+  assert line['config']['blocks'] == '2x2x2'
+  assert line['config']['dof_count_via_exchange_ok'] is True
+  # rank 0 holds the corner block: 3 faces of 7^2, minus overlaps counted per
+  # neighbour -> faces 3 * 49, edges 3 * 7, corner 1 values sent
+  assert line['config']['interface_values_sent_rank0'] == 3 * 49 + 3 * 7 + 1
+  assert line['config']['dofs_global'] == 13 ** 3
+
+
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
   import subprocess
   import sys

@@ -129,12 +129,19 @@ def test_facet_table_reproduces_the_index_rows(P):
 
 @pytest.mark.parametrize('P', [6, 7, 8])
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
-def test_facet_helmholtz_matches_oracle(P, dtype, monkeypatch):
+@pytest.mark.parametrize('chain', ['16', '3', 'off'])
+def test_facet_helmholtz_matches_oracle(P, dtype, chain, monkeypatch):
+  """`chain`: scalar fields walk chains of elements (segments of <= 16 / 3
+  elements, the shared face carried in registers) or one element per wave."""
   tol = TOL[dtype]
+  if chain == 'off':
+    monkeypatch.setenv('SFEM_CHAIN', '0')
+  else:
+    monkeypatch.setenv('SFEM_CHAIN_LEN', chain)
   for mode, rotate in (('structured', False), ('stretched', True),
                        ('sheared', True), ('jittered', True)):
     rng = np.random.default_rng(100 * P + len(mode))
-    rp = make_mesh(2, P, mode, rng, rotate)
+    rp = make_mesh(3 if chain == '3' and P == 6 else 2, P, mode, rng, rotate)
     mesh = rp.finalize(device=DEV, dtype=dtype)
     fes = FiniteElementSpace.create(
         mesh, Quadrature1D.create_from_nodes_1d(Nodes1D.create(P, GLL)))
@@ -150,6 +157,18 @@ def test_facet_helmholtz_matches_oracle(P, dtype, monkeypatch):
     for g, op in ops.items():
       assert op.facet_parts is not None, (mode, g)
       assert all('facet_table' in p for p in op.facet_parts), (mode, g)
+      chained = [p for p in op.facet_parts if 'chains' in p]
+      light = [p for p in op.facet_parts
+               if p['geo_mode'] in (_lib.GEO_BOX, _lib.GEO_AFFINE)]
+      assert len(chained) == len(light), (mode, g)
+      if chain == 'off' or not chained:
+        assert 'helmholtz_facet_kernel' in op.kernel_name()
+      else:
+        assert 'helmholtz_chain_kernel' in op.kernel_name()
+        if not rotate:      # structured n^3 mesh: n^2 chains of n
+          off = op.facet_parts[0]['chains'][0]
+          n = round(mesh.num_elements ** (1 / 3))
+          assert off.tolist() == list(range(0, n ** 3 + 1, n))
     kinds = {p['geo_mode'] for p in ops['auto'].facet_parts}
     if dtype == torch.float64:
       want = {'structured': {_lib.GEO_BOX}, 'stretched': {_lib.GEO_BOX},

@@ -39,9 +39,15 @@ def test_coefficients_and_errors():
   np.testing.assert_allclose(bdfk_coeffs(3), [-1 / 3, 3 / 2, -3, 11 / 6],
                              atol=1e-12)
   np.testing.assert_allclose(extk_coeffs(2), [1, -3, 3], atol=1e-12)
+  # exact rationals here, barycentric evaluation in the reference / oracle:
+  # equal to rounding (the reference's own values carry ~1e-15)
   for k in range(1, 5):
-    np.testing.assert_array_equal(bdfk_coeffs(k), O.bdfk_coeffs(k))
-    np.testing.assert_array_equal(extk_coeffs(k), O.extk_coeffs(k))
+    np.testing.assert_allclose(bdfk_coeffs(k), O.bdfk_coeffs(k), rtol=0,
+                               atol=1e-13)
+    np.testing.assert_allclose(extk_coeffs(k), O.extk_coeffs(k), rtol=0,
+                               atol=1e-13)
+  np.testing.assert_array_equal(bdfk_coeffs(2), [0.5, -2.0, 1.5])
+  np.testing.assert_array_equal(extk_coeffs(3), [-1.0, 4.0, -6.0, 4.0])
   from swirl_fem_amd.core.interpolation import Nodes1D, NodeType
   from swirl_fem_amd.core.mesh_refiner import refine_premesh
   hi = refine_premesh(SC.make_premesh(2), Nodes1D.create(

@@ -678,3 +678,48 @@ def test_rcb_order_groups():
     counts = np.bincount(g)
     assert counts.max() <= leaf and len(counts) == g[-1] + 1
     assert len(counts) <= -(-M // leaf) + max(0, int(np.log2(max(M, 2))))
+
+
+def test_facet_chains_contract():
+  """`operators.facet_chains` (host logic of the chain launches): every
+  element once, segments no longer than asked, and inside a segment the face
+  a = P-1 of an element is the face a = 0 of the next, node for node."""
+  import itertools
+  import torch
+  from swirl_fem_amd.core import operators
+  rng = np.random.default_rng(3)
+  P = 4
+  nodes = I.Nodes1D.create(P, NT['gll'])
+  base = unit_cube_mesh(3, ndim=3)
+  orients = [(perm, axes) for perm in itertools.permutations(range(3))
+             for r in range(4) for axes in itertools.combinations(range(3), r)]
+  rot = []
+  for e in base.elements[rng.permutation(base.num_elements)]:
+    perm, axes = orients[rng.integers(len(orients))]
+    rot.append(np.flip(e.reshape(2, 2, 2).transpose(perm), axes).reshape(-1))
+  cases = {'structured': base,
+           'rotated': base.replace(elements=np.array(rot, dtype=np.int32))}
+  for name, pm in cases.items():
+    el = torch.as_tensor(refine_premesh(pm, nodes).elements)
+    E, n2 = el.shape[0], P * P
+    for ids in (torch.arange(E), torch.arange(0, E, 2), torch.tensor([5])):
+      for seg_len in (2, 3, 16):
+        off, elems = operators.facet_chains(el, ids, P, seg_len)
+        off, elems = off.numpy(), elems.numpy()
+        assert sorted(elems.tolist()) == sorted(ids.tolist()), name
+        assert off[0] == 0 and off[-1] == len(elems)
+        assert (np.diff(off) >= 1).all() and (np.diff(off) <= seg_len).all()
+        links = 0
+        for s in range(len(off) - 1):
+          for k in range(off[s], off[s + 1] - 1):
+            x, y = elems[k], elems[k + 1]
+            assert np.array_equal(el[x, (P - 1) * n2:].numpy(),
+                                  el[y, :n2].numpy()), (name, x, y)
+            links += 1
+        if name == 'structured' and len(ids) == E and seg_len == 16:
+          assert links == 18 and len(off) - 1 == 9     # nine chains of three
+  # a closed ring of elements (no head): its members walk alone
+  ring = torch.tensor([[0, 1, 2, 3, 4, 5, 6, 7], [4, 5, 6, 7, 0, 1, 2, 3]],
+                      dtype=torch.int32)
+  off, elems = operators.facet_chains(ring, torch.arange(2), 2, 16)
+  assert off.tolist() == [0, 1, 2] and sorted(elems.tolist()) == [0, 1]

@@ -389,6 +389,8 @@ def test_cpu_reference_matches_oracle():
   u = rng.standard_normal(rp.num_nodes)
   got = ref.apply(torch.from_numpy(u)).numpy()
   assert np.abs(got - A(u)).max() < 1e-13 * np.abs(A(u)).max()
+  got = ref.apply_sum_factorised(torch.from_numpy(u)).numpy()
+  assert np.abs(got - A(u)).max() < 1e-13 * np.abs(A(u)).max()
   b = (1 - mask) * u
   x, k, _ = ref.cg_iterations(torch.from_numpy(b), iters=25)
   xo, _ = O.cg(A, b, tol=0.0, maxiter=25)
