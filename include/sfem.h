@@ -272,7 +272,9 @@ typedef struct sfem_helmholtz_args {
                                   /*   id | SFEM_IDX_DIRICHLET | SFEM_IDX_    */
                                   /*   SHARED (= also held by an element      */
                                   /*   outside the cluster); at most          */
-                                  /*   max_shared entries per cluster         */
+                                  /*   max_shared entries per cluster (from   */
+                                  /*   sfem_helmholtz_cluster_limits; longer  */
+                                  /*   tables are truncated by the kernel)    */
   int64_t num_clusters;           /* `enc` must then be in cluster form: a    */
                                   /*   slot whose node is in the table holds  */
                                   /*   SFEM_IDX_SHARED | DIRICHLET bit | its  */
@@ -426,7 +428,9 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  * Preconditioned CG of linalg/cg.py:30-97 with device-resident scalars: no
  * host synchronisation inside an iteration (the reference keeps its loop on
  * device with lax.while_loop, cg.py:94-95).  `scalars` is a device array of
- * SFEM_CG_NSCALARS doubles:
+ * SFEM_CG_NSCALARS (= 80) doubles -- ALL of them are read and written by the
+ * update kernels and the scalar phases (ABI <= 2 callers allocated 16: they
+ * must grow the array):
  *   [0] gamma = r.M r   [1] p.Ap   [2] gamma_new   [3] alpha   [4] beta
  *   [5] b.b   [6] atol2 = max(tol^2 b.b, atol^2)   [7] done (0/1)
  *   [8] iterations   [9] an iteration is open (phases 5 / 6)
@@ -434,11 +438,13 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *        reference's stop rule (cg.py:68-73, which reads a negative or NaN
  *        r.Mr as "converged" and divides by any p.Ap) the solve stops with
  *        BAD_GAMMA when r.Mr is negative or not finite and with BAD_PAP when
- *        p.Ap is not positive and finite (checked before that iteration's
- *        updates, so x is the last good iterate).
+ *        p.Ap is zero or not finite (checked before that iteration's updates,
+ *        so x is the last good iterate); a negative p.Ap is divided by, as in
+ *        the reference.
  * Once `done` is set every kernel below is a no-op, so the host may run ahead
- * and poll [7] asynchronously; the iterate and the iteration count are exactly
- * those of a loop that tests the condition of cg.py:68-73 every iteration.
+ * and poll [7] asynchronously; unless one of the two breakdowns occurs, the
+ * iterate and the iteration count are exactly those of a loop that tests the
+ * condition of cg.py:68-73 every iteration.
  *
  * sfem_dot:            *result  = sum a*b          (clears result first)
  * sfem_dot_accumulate: *result += sum a*b

@@ -610,8 +610,12 @@ static void launch_update_r(int fuse_rr, bool nt, int grid, hipStream_t stream,
 __device__ __forceinline__ bool cg_bad_gamma(double g) {
   return !(g >= 0.0) || !(g <= 1.7976931348623157e308);
 }
+// p.Ap: any finite non-zero value is divided by, as in the reference
+// (cg.py:78-79; a negative definite A converges like its negative); zero and
+// non-finite values stop the solve.
 __device__ __forceinline__ bool cg_bad_pap(double v) {
-  return !(v > 0.0) || !(v <= 1.7976931348623157e308);
+  return v == 0.0 || !(v >= -1.7976931348623157e308) ||
+         !(v <= 1.7976931348623157e308);
 }
 // closes an iteration: beta, gamma <- gamma_new, counter, stop test
 __device__ __forceinline__ void cg_close_iteration(double* scalars,
@@ -635,8 +639,8 @@ __device__ __forceinline__ void cg_close_iteration(double* scalars,
     scalars[7] = 1.0;
   }
 }
-// alpha = gamma / p.Ap, or stop (before this iteration's updates) when the
-// operator is not positive along p
+// alpha = gamma / p.Ap, or stop (before this iteration's updates) when p.Ap
+// is zero or not finite
 __device__ __forceinline__ void cg_set_alpha(double* scalars, double pap) {
   if (cg_bad_pap(pap)) {
     scalars[10] = SFEM_CG_STATUS_BAD_PAP;

@@ -288,6 +288,7 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
     // p = 11 fp32: the contractions on the matrix cores, opt-in (SFEM_MFMA=1):
     // measured 1.25 vs 1.0 ms for the vector-ALU kernel at 48^3 elements
     // (profiles/r02_mfma_notes.md), so not the default
+    // (read per launch: the tests switch it inside one process; ~0.1 us)
     const char* v = getenv("SFEM_MFMA");
     const bool mfma_on = v && v[0] == '1';
     if (mfma_on && helmholtz_mfma_applies(prm, c.P, c.ndim, c.gs))

@@ -128,7 +128,11 @@ helmholtz_cluster_kernel(DMat<T, P> dm, HelmholtzParams<T> prm,
   const bool active = eid >= 0;
   const int64_t e = active ? eid : 0;
   const int off0 = cl.offsets[c];
-  const int K = cl.offsets[c + 1] - off0;
+  // a table longer than the strip (a caller that ignored
+  // sfem_helmholtz_cluster_limits) must not run over the LDS: the surplus
+  // entries are dropped (the result is then wrong, the memory stays intact)
+  const int Kraw = cl.offsets[c + 1] - off0;
+  const int K = Kraw < KMAX ? (Kraw > 0 ? Kraw : 0) : KMAX;
   // lanes on the rim of the (i, j) lattice; inner lanes own interior nodes in
   // the slices 1 .. P-2
   const bool edge = i == 0 || i == P - 1 || j == 0 || j == P - 1;

@@ -406,7 +406,9 @@ helmholtz_mfma_p12_kernel(MfmaConsts<12> cst, HelmholtzParams<float> prm) {
 // True if the matrix-core kernel covers this launch.
 inline bool helmholtz_mfma_applies(const HelmholtzParams<float>& prm, int P,
                                    int ndim, bool gs) {
-  return gs && ndim == 3 && P == 12 && prm.ncomp == 1 && !prm.colored &&
+  // the kernel addresses u / out as dense scalar fields
+  return gs && ndim == 3 && P == 12 && prm.ncomp == 1 &&
+         prm.node_stride == 1 && prm.comp == 0 && !prm.colored &&
          (prm.geo_mode == GEO_AFFINE || prm.geo_mode == GEO_MULTILINEAR) &&
          prm.geo_elem && prm.weights_host && prm.nodes_host;
 }

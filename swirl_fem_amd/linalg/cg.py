@@ -273,7 +273,7 @@ class CGRunner:
     # (cg.py:96-97); 'status' says why the loop ended: 'converged', 'maxiter',
     # or a breakdown the reference would have reported as convergence
     # ('breakdown_gamma': r.Mr negative / not finite, 'breakdown_pAp': p.Ap
-    # not positive) -- x is then the last iterate, NOT a solution to `tol`.
+    # zero / not finite) -- x is then the last iterate, NOT a solution to `tol`.
     return {'residual': self.s.t[_Scalars.GAMMA].clone(),
             'num_iterations': int(scal[_Scalars.ITERS].item()),
             'status': status}
@@ -321,7 +321,16 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
       run.step()
     if run.done():
       break
-  return run.x, run.info()
+  info = run.info()
+  if info['status'].startswith('breakdown'):
+    # the reference would have returned this as a converged solve; callers
+    # that ignore `info` (the Stokes solves) at least get told
+    import warnings
+    warnings.warn(f"cg stopped with status '{info['status']}' after "
+                  f"{info['num_iterations']} iterations: x is the last "
+                  'iterate, not a solution to the requested tolerance',
+                  RuntimeWarning, stacklevel=2)
+  return run.x, info
 
 
 class _SymmetricSolve(torch.autograd.Function):

@@ -106,7 +106,10 @@ def _load():
       'H5Eset_auto2': (ctypes.c_int, [hid, ctypes.c_void_p, ctypes.c_void_p]),
   }
   for name, (res, args) in sig.items():
-    fn = getattr(lib, name)
+    try:
+      fn = getattr(lib, name)
+    except AttributeError as exc:   # e.g. a build without the 1.6 API
+      raise H5Error(f'libhdf5 lacks {name}: {exc}') from exc
     fn.restype, fn.argtypes = res, args
   lib.H5Eset_auto2(0, None, None)           # errors come back as status codes
   lib._hid = hid
@@ -178,11 +181,13 @@ def read(path: str) -> dict:
   try:
     root = lib.H5Gopen2(f, b'/', _H5P_DEFAULT)
     count = ctypes.c_uint64(0)
-    lib.H5Gget_num_objs(root, ctypes.byref(count))
+    if root < 0 or lib.H5Gget_num_objs(root, ctypes.byref(count)) < 0:
+      raise H5Error(f'cannot list the root group of {path}')
     names = []
     for k in range(count.value):
       buf = ctypes.create_string_buffer(1024)
-      lib.H5Gget_objname_by_idx(root, k, buf, 1024)
+      if lib.H5Gget_objname_by_idx(root, k, buf, 1024) < 0:
+        raise H5Error(f'cannot read the name of object {k} of {path}')
       names.append(buf.value)
     lib.H5Gclose(root)
     for name in names:

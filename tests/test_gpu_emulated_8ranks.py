@@ -244,6 +244,8 @@ def test_partitioned_cg_on_the_triply_periodic_box(monkeypatch, grid):
                       'maxiter'), tight
     if status == 'converged':
       assert residual >= 0.0 and err < 1e-8, tight
+    else:   # stopped early: still at least the loose-tolerance answer
+      assert err < 1e-6, tight
     if status == 'breakdown_gamma':
       assert not residual >= 0.0, tight
     assert residual >= 0.0 or status != 'converged', tight

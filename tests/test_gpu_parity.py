@@ -886,9 +886,18 @@ def test_cg_reports_breakdown_instead_of_convergence():
   assert info['status'] == 'converged' and info['num_iterations'] == 1
   x, info = cg(lambda x: 3 * x + 0 * x.sum(), b, tol=0.0, maxiter=0)
   assert info['status'] == 'maxiter' and info['num_iterations'] == 0
-  # negative definite operator: p.Ap < 0 at the first iteration; x stays x0
+  # negative definite operator: the reference divides by any p.Ap (cg.py:
+  # 78-79) and converges; so does this solve, with the oracle's iterates
   x0 = dev(np.full(6, 0.25))
-  x, info = cg(lambda x: -2 * x, b, x0=x0)
+  Aneg = -np.diag([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+  x, info = cg(lambda x: dev(Aneg) @ x, b, x0=x0, tol=1e-12)
+  xo, io = O.cg(lambda v: Aneg @ v, b.cpu().numpy(), x0=x0.cpu().numpy(),
+                tol=1e-12)
+  assert info['status'] == 'converged'
+  assert info['num_iterations'] == io['num_iterations']
+  assert relerr(x, xo) < 1e-12
+  # p.Ap exactly zero: the solve stops before the update; x stays x0
+  x, info = cg(lambda x: 0 * x, b, x0=x0)
   assert info['status'] == 'breakdown_pAp' and info['num_iterations'] == 0
   np.testing.assert_array_equal(x.cpu().numpy(), x0.cpu().numpy())
   # indefinite "preconditioner": r.Mr < 0 before the first iteration
@@ -913,11 +922,15 @@ def test_cg_reports_breakdown_instead_of_convergence():
   op = fes.helmholtz_operator(mesh.physical_masks['boundary'])
   rhs = dev(np.random.default_rng(1).standard_normal(mesh.num_nodes)) * (
       ~mesh.physical_masks['boundary'])
-  x, info = cg(op.linear_operator(0.0, -1.0), rhs, tol=1e-10)
-  assert info['status'] == 'breakdown_pAp' and info['num_iterations'] == 0
-  assert float(x.abs().max()) == 0.0
   x, info = cg(op.linear_operator(0.0, 1.0), rhs, tol=1e-10)
   assert info['status'] == 'converged'
+  xm, infom = cg(op.linear_operator(0.0, -1.0), rhs, tol=1e-10)   # -A
+  assert infom['status'] == 'converged'
+  assert infom['num_iterations'] == info['num_iterations']
+  assert float((xm + x).abs().max()) <= 1e-12 * float(x.abs().max())
+  x, info = cg(op.linear_operator(0.0, 0.0), rhs, tol=1e-10)      # zero
+  assert info['status'] == 'breakdown_pAp' and info['num_iterations'] == 0
+  assert float(x.abs().max()) == 0.0
 
 
 def test_cg_with_fused_operator_dot():
