@@ -280,7 +280,7 @@ typedef struct sfem_helmholtz_args {
                                   /*   SFEM_IDX_SHARED | DIRICHLET bit | its  */
                                   /*   POSITION in the table, other slots     */
                                   /*   id | DIRICHLET bit; elem_list unused   */
-  /* apply, 3D, P = 6..8: compact connectivity (NULL = off, `enc` is then     */
+  /* apply, 3D, P = 6..12: compact connectivity (NULL = off, `enc` is then    */
   /* required).  (E, 27, 4) int32 from sfem_facet_table_build; every listed   */
   /* element must have qualified there.  `enc`, `shared_order` are not read.  */
   /* Needs node_stride = 1 (scalar or component-major fields).                */

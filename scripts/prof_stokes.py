@@ -1,0 +1,48 @@
+"""Driver for rocprofv3: the fused Stokes divergence / pressure-gradient
+kernels (navier_stokes.py:313-338) on the config-4 GPU block: n^3 elements,
+p = 7 velocity / P - 2 Gauss pressure, component-major velocity, per-node scale
+folded into the divergence (the two kernels of one application of E).
+Prints one JSON line with HIP-event times and the bytes each launch must move.
+env: N (64), P (8), REPS (10)"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+from swirl_fem_amd.core import layout, operators
+from swirl_fem_amd.core.fespace import FiniteElementSpace
+from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
+from swirl_fem_amd.core.mesh_refiner import refine_premesh
+n = int(os.environ.get('N', '64')); P = int(os.environ.get('P', '8'))
+reps = int(os.environ.get('REPS', '10'))
+dev = 'cuda:0'
+pm = unit_cube_mesh(n, ndim=3)
+quad = Quadrature1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
+vsp = FiniteElementSpace.create(refine_premesh(pm, Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)).finalize(device=dev), quad)
+psp = FiniteElementSpace.create(refine_premesh(pm, Nodes1D.create(P - 2, NodeType.GAUSS_LEGENDRE)).finalize(device=dev), quad)
+N, E = vsp.mesh.num_nodes, vsp.mesh.num_elements
+nn, npp, s = P ** 3, (P - 2) ** 3, 8
+op = operators.StokesDivGrad.create(vsp, psp, vsp.mesh.physical_masks['boundary'], 'auto')
+u = layout.component_major(torch.randn(N, 3, dtype=torch.float64, device=dev))
+scale = torch.rand(N, dtype=torch.float64, device=dev) + 0.5
+p = torch.randn(psp.mesh.num_nodes, dtype=torch.float64, device=dev)
+pout, out = torch.empty_like(p), torch.empty_like(u)
+so = 0 if op.shared_order is None else 2 * op.shared_order.shape[1]
+# bytes a launch has to move (affine / multilinear geometry: 24 reals per element)
+must = {
+    'stokes_div': 4 * E * nn + 3 * s * N + s * N + 24 * s * E + s * E * npp,
+    'stokes_grad_t': 4 * E * nn + so * E + s * E * npp + 24 * s * E + 3 * s * N,
+}
+def timeit(fn):
+  for _ in range(3): fn()
+  torch.cuda.synchronize()
+  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+  for a, b in ev:
+    a.record(); fn(); b.record()
+  torch.cuda.synchronize()
+  return sum(a.elapsed_time(b) for a, b in ev) / reps
+res = {'n': n, 'P': P, 'velocity_dofs': 3 * N, 'pressure_dofs': E * npp,
+       'stokes_div': {'ms': timeit(lambda: op.div(u, scale=scale, out=pout)), 'bytes_must_move': must['stokes_div']},
+       'stokes_grad_t': {'ms': timeit(lambda: op.grad_t(p, out=out)), 'bytes_must_move': must['stokes_grad_t']}}
+for k in ('stokes_div', 'stokes_grad_t'):
+  res[k]['frac_of_8TBs'] = res[k]['bytes_must_move'] / (res[k]['ms'] * 1e-3) / 8e12
+print(json.dumps(res))

@@ -93,7 +93,7 @@ def classify_geometry(fespace):
 
 
 _GEO_POINT, _GEO_AFFINE, _GEO_MULTILINEAR, _GEO_BOX = 0, 1, 3, 5
-FACET_P = (6, 7, 8)           # orders the facet-table kernels are compiled for
+FACET_P = tuple(range(6, 13))  # orders the facet-table kernels are compiled for
 BOX_TOL = {torch.float64: 1e-13, torch.float32: 5e-7}
 
 
@@ -183,7 +183,9 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
       # chains pay where the element arithmetic is light (box / affine:
       # 0.72 -> 0.58 / 0.66 ms at config 2); the multilinear and stored-factor
       # kernels have no registers left for the look-ahead (measured slower)
-      if seg_len > 1 and mode in (_GEO_BOX, _GEO_AFFINE):
+      # ... and elements that span several waves (P >= 9: the chain kernels
+      # run at 2 waves per SIMD there; p = 11 fp32 box 1.74 vs 1.46 ms)
+      if seg_len > 1 and mode in (_GEO_BOX, _GEO_AFFINE) and P <= 8:
         new['chains'] = facet_chains(mesh.elements, ids, P, seg_len)
         new['chain_len'] = seg_len
     out.append(new)
@@ -193,6 +195,11 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
     ids = every if 'elem_list' not in part else part['elem_list'].long()
     good = ok[ids]
     mode = part['geo_mode']
+    if mode == _GEO_MULTILINEAR and P >= 9:
+      # 12 nodes per lane plus the multilinear geometry state need 203 VGPRs
+      # on the facet kernel (2 waves per SIMD): measured 3.97 vs 2.99 ms for
+      # the index-row kernel at p = 11 fp32, which therefore keeps them
+      good = torch.zeros_like(good)
     if mode == _GEO_AFFINE:
       if cst is None:
         cst = _ops.helmholtz_setup_affine(coef, BOX_TOL[fespace.dtype])

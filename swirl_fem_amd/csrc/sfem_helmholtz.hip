@@ -433,7 +433,7 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
   }
   if (a->facet_table) {
     SFEM_REQUIRE(a->ndim == 3 && facet_supported_p(a->P),
-                 "sfem_helmholtz_apply: facet tables are 3D, P = 6..8");
+                 "sfem_helmholtz_apply: facet tables are 3D, P = 6..12");
     SFEM_REQUIRE(!a->colored && !a->cluster_elems,
                  "sfem_helmholtz_apply: facet tables exclude colored / "
                  "cluster assembly");

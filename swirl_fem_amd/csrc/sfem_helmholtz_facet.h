@@ -67,49 +67,60 @@ struct FacetParams {
   double* dot_out;
 };
 
-// Where node (x, y, z) of an element sits in its LDS copy (in words of T).
+// Where node (x, y, z) of an element sits in its LDS copy (in words of T), and
+// the shape of the workgroup: one element, ceil(P^2 / 64) waves.
 template <int P>
 struct FacetLayout {
-  static constexpr int A = P == 8 ? 67 : (P == 7 ? 52 : P * P);
-  static constexpr int B = P;
+  // P = 8: see the header comment; P >= 9 (several waves per element): rows
+  // padded to an odd length as in the index-row kernel
+  static constexpr int B = P >= 9 ? (P | 1) : P;
+  static constexpr int A = P == 8 ? 67 : (P == 7 ? 52 : P * B);
   static constexpr bool SWAP = P == 8;   // transposed passes: lane (i, j) takes
                                          // the line with first index j
   static constexpr int WORDS = (P - 1) * (A + B + 1) + 1;
-  static constexpr int COPY = (WORDS + 1) & ~1;
+  static constexpr int COPY = (WORDS + 3) & ~3;
+  static constexpr int TPE = P * P;
+  static constexpr int WAVES = (TPE + 63) / 64;
+  static constexpr int BLOCK = 64 * WAVES;
   __host__ __device__ static constexpr int word(int x, int y, int z) {
     return A * x + B * y + z;
   }
 };
 
-// Shared scatter: in round q the lanes of the wave take one face interior
+// Orders the LDS traffic of the element's lanes: a compiler fence inside one
+// wave, a workgroup barrier (LDS only, see lds_barrier) across several.
+template <int P>
+__device__ __forceinline__ void facet_sync() {
+  if (FacetLayout<P>::WAVES == 1) wave_sync();
+  else lds_barrier();
+}
+
+// Shared scatter: in round q the lanes of the element take one face interior
 // ((P-2)^2 lanes), two edge interiors (2 (P-2) lanes) and -- round 0 -- the
 // eight vertices, so that one atomic instruction covers whole contiguous node
-// blocks.  slot[lane][q] = LDS word of the node the lane handles, 0xFFFF none.
-struct alignas(16) FacetSlots {
-  uint32_t pk[64][4];   // slots 2k, 2k+1 of a lane in the halves of pk[lane][k]
-  void set(int lane, int q, unsigned w) {
-    const unsigned sh = 16 * (q & 1);
-    pk[lane][q >> 1] = (pk[lane][q >> 1] & ~(0xFFFFu << sh)) | (w << sh);
-  }
+// blocks.  s[lane][q] = LDS word of the node the lane handles, 0xFFFF none.
+template <int P>
+struct FacetSlots {
+  uint16_t s[FacetLayout<P>::BLOCK][6];
 };
 
 template <int P>
-inline FacetSlots make_facet_slots() {
+constexpr FacetSlots<P> make_facet_slots() {
   using L = FacetLayout<P>;
-  FacetSlots s;
-  for (int l = 0; l < 64; ++l)
-    for (int k = 0; k < 4; ++k) s.pk[l][k] = 0xFFFFFFFFu;
+  FacetSlots<P> t{};
+  for (int l = 0; l < L::BLOCK; ++l)
+    for (int q = 0; q < 6; ++q) t.s[l][q] = 0xFFFF;
   constexpr int M = P - 2, NF = M * M;
-  static_assert(NF + 2 * M + 8 <= 64, "one wave per element");
+  static_assert(NF + 2 * M + 8 <= L::TPE, "rounds must fit the element's lanes");
   // edges: 4 along j, 4 along i, 4 along a
-  int edges[12][3];   // fixed coordinates, -1 = running
+  int edges[12][3] = {};   // fixed coordinates, -1 = running
   int ne = 0;
   for (int d = 2; d >= 0; --d)
-    for (int p = 0; p < 2; ++p)
+    for (int pp = 0; pp < 2; ++pp)
       for (int r = 0; r < 2; ++r) {
-        int c[3];
+        int c[3] = {0, 0, 0};
         c[d] = -1;
-        c[(d + 1) % 3] = p ? P - 1 : 0;
+        c[(d + 1) % 3] = pp ? P - 1 : 0;
         c[(d + 2) % 3] = r ? P - 1 : 0;
         for (int k = 0; k < 3; ++k) edges[ne][k] = c[k];
         ++ne;
@@ -118,26 +129,28 @@ inline FacetSlots make_facet_slots() {
     const int d = q / 2, fixed = (q & 1) ? P - 1 : 0;   // face normal axis d
     for (int l = 0; l < NF; ++l) {
       const int x = l / M + 1, y = l % M + 1;
-      int c[3];
+      int c[3] = {0, 0, 0};
       c[d] = fixed;
       c[(d + 1) % 3] = d == 1 ? y : x;   // keep (x, y) in ascending axis order
       c[(d + 2) % 3] = d == 1 ? x : y;
-      s.set(l, q, (unsigned)L::word(c[0], c[1], c[2]));
+      t.s[l][q] = (uint16_t)L::word(c[0], c[1], c[2]);
     }
     for (int h = 0; h < 2; ++h)
       for (int z = 0; z < M; ++z) {
-        const int* ed = edges[2 * q + h];
-        int c[3];
-        for (int k = 0; k < 3; ++k) c[k] = ed[k] < 0 ? z + 1 : ed[k];
-        s.set(NF + h * M + z, q, (unsigned)L::word(c[0], c[1], c[2]));
+        int c[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k)
+          c[k] = edges[2 * q + h][k] < 0 ? z + 1 : edges[2 * q + h][k];
+        t.s[NF + h * M + z][q] = (uint16_t)L::word(c[0], c[1], c[2]);
       }
   }
   for (int v = 0; v < 8; ++v)
-    s.set(NF + 2 * M + v, 0,
-          (unsigned)L::word((v & 4) ? P - 1 : 0, (v & 2) ? P - 1 : 0,
-                            (v & 1) ? P - 1 : 0));
-  return s;
+    t.s[NF + 2 * M + v][0] = (uint16_t)L::word(
+        (v & 4) ? P - 1 : 0, (v & 2) ? P - 1 : 0, (v & 1) ? P - 1 : 0);
+  return t;
 }
+
+template <int P>
+__device__ const FacetSlots<P> g_facet_slots = make_facet_slots<P>();
 
 // Centrosymmetric P x P matrix (K[P-1-r][P-1-m] = K[r][m]) in even/odd form:
 //   xe = x[m] + x[P-1-m], xo = x[m] - x[P-1-m]  (m < PH),  xe[PH] = x[PH]
@@ -194,6 +207,36 @@ __device__ __forceinline__ void sym_line_apply(const SMat<T, P>& sm,
     if (r < PH) {
 #pragma unroll
       for (int m = 0; m < PH; ++m) so += sm.o[r * PH + m] * xo[m];
+      y[r] = se + so;
+      y[P - 1 - r] = se - so;
+    } else {
+      y[r] = se;
+    }
+  }
+}
+
+// The same product with the matrix re-read from the kernarg segment per product
+// (fp32, P >= 9: see line_apply_mem).
+template <typename T, int P>
+__device__ __forceinline__ void sym_line_apply_mem(
+    const SFEM_CONSTANT_AS SMat<T, P>* km, const T (&x)[P], T (&y)[P]) {
+  constexpr int PH = P / 2, PC = P - P / 2;
+  asm volatile("" : "+s"(km));
+  T xe[PC], xo[PH > 0 ? PH : 1];
+#pragma unroll
+  for (int m = 0; m < PH; ++m) {
+    xe[m] = x[m] + x[P - 1 - m];
+    xo[m] = x[m] - x[P - 1 - m];
+  }
+  if (PC > PH) xe[PH] = x[PH];
+#pragma unroll
+  for (int r = 0; r < PC; ++r) {
+    T se = T(0), so = T(0);
+#pragma unroll
+    for (int m = 0; m < PC; ++m) se += km->e[r * PC + m] * xe[m];
+    if (r < PH) {
+#pragma unroll
+      for (int m = 0; m < PH; ++m) so += km->o[r * PH + m] * xo[m];
       y[r] = se + so;
       y[P - 1 - r] = se - so;
     } else {
@@ -280,12 +323,12 @@ __device__ __forceinline__ void facet_scatter_head(const FacetLane<P>& fl,
 // resp. uint32.
 template <typename T, int P, bool OFF32>
 __device__ __forceinline__ void facet_scatter_tail(
-    const FacetLane<P>& fl, const uint32_t (&slots)[3], const T (&acc)[P],
-    T* og, T* vals, uint32_t* codes, uint32_t own_w) {
+    const FacetLane<P>& fl, const uint16_t (&slots)[6], const T (&acc)[P],
+    T* og, T* vals, uint32_t* codes, uint32_t own_w, bool lane_ok) {
   using L = FacetLayout<P>;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    if (!(fl.t[c] & SFEM_IDX_SHARED)) {
+    if (lane_ok && !(fl.t[c] & SFEM_IDX_SHARED)) {
 #pragma unroll
       for (int a = 0; a < P; ++a)
         if (FacetLane<P>::cls(a) == c) {
@@ -298,21 +341,23 @@ __device__ __forceinline__ void facet_scatter_tail(
     }
   }
   // shared nodes: values and codes change lanes through LDS
+  if (lane_ok) {
 #pragma unroll
-  for (int a = 0; a < P; ++a) {
-    vals[own_w + a * L::A] = acc[a];
-    codes[own_w + a * L::A] = fl.code(a);
+    for (int a = 0; a < P; ++a) {
+      vals[own_w + a * L::A] = acc[a];
+      codes[own_w + a * L::A] = fl.code(a);
+    }
   }
-  wave_sync();
+  facet_sync<P>();
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
-    const uint32_t w = (slots[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+    const uint32_t w = slots[q];
     if (w != 0xFFFFu) {
       const uint32_t code = codes[w];
 #if SFEM_FACET_TIMING == 7        // timing only: no edge / vertex atomics
-      if ((threadIdx.x & 63) >= (P - 2) * (P - 2)) continue;
+      if ((int)threadIdx.x >= (P - 2) * (P - 2)) continue;
 #elif SFEM_FACET_TIMING == 8      // timing only: no face atomics
-      if ((threadIdx.x & 63) < (P - 2) * (P - 2)) continue;
+      if ((int)threadIdx.x < (P - 2) * (P - 2)) continue;
 #endif
       if ((code & ~(uint32_t)SFEM_IDX_MASK) == SFEM_IDX_SHARED) {
 #if SFEM_FACET_TIMING == 3 || SFEM_FACET_TIMING == 6     // timing only
@@ -327,24 +372,12 @@ __device__ __forceinline__ void facet_scatter_tail(
   }
 }
 
-template <typename T, int P, bool OFF32>
-__device__ __forceinline__ void facet_scatter(
-    const FacetLane<P>& fl, const uint32_t (&slots)[3], T (&acc)[P],
-    const T (&ua)[P], T* og, T* vals, uint32_t* codes, uint32_t own_w,
-    bool want_dot, double& udot) {
-  facet_scatter_head<T, P>(fl, acc, ua, want_dot, udot);
-  facet_scatter_tail<T, P, OFF32>(fl, slots, acc, og, vals, codes, own_w);
-}
-
-// Kernel-argument offsets (the matrices and the slot table are read through
-// the kernarg segment with lane-dependent indices).
+// Kernel-argument offset of the matrices (read through the kernarg segment
+// with lane-dependent indices, and as scalar memory for P >= 9 in fp32).
 template <typename PRM, typename MAT>
 struct FacetKernarg {
   static constexpr size_t MAT_OFF =
       (sizeof(PRM) + alignof(MAT) - 1) / alignof(MAT) * alignof(MAT);
-  static constexpr size_t SLOT_OFF =
-      (MAT_OFF + sizeof(MAT) + alignof(FacetSlots) - 1) / alignof(FacetSlots) *
-      alignof(FacetSlots);
 };
 
 __device__ __forceinline__ const char* kernarg_bytes() {
@@ -382,12 +415,45 @@ __device__ __forceinline__ T sym_w(const M& m, int a) {
   return m.w[a < P - 1 - a ? a : P - 1 - a];
 }
 
-// Lane constants of a one-wave element.
+// y = D x / D^T x with the matrix taken from the by-value kernel argument, or
+// (fp32, P >= 9: 72 entries do not fit the SGPRs next to everything else, see
+// line_apply_mem) re-read from the kernarg segment per product.
+template <typename T, int P, bool TRANS, typename PRM>
+__device__ __forceinline__ void facet_line(const DMat<T, P>& dm,
+                                           const T (&x)[P], T (&y)[P]) {
+  if constexpr (P >= 9 && sizeof(T) == 4) {
+    using KA = FacetKernarg<PRM, DMat<T, P>>;
+    line_apply_mem<T, P, TRANS>(
+        (const SFEM_CONSTANT_AS DMat<T, P>*)((const SFEM_CONSTANT_AS char*)
+                                                 __builtin_amdgcn_kernarg_segment_ptr() +
+                                             KA::MAT_OFF),
+        x, y);
+  } else {
+    line_apply<T, P, TRANS>(dm, x, y);
+  }
+}
+
+template <typename T, int P, typename PRM>
+__device__ __forceinline__ void facet_sym_line(const SMat<T, P>& sm,
+                                               const T (&x)[P], T (&y)[P]) {
+  if constexpr (P >= 9 && sizeof(T) == 4) {
+    using KA = FacetKernarg<PRM, SMat<T, P>>;
+    sym_line_apply_mem<T, P>(
+        (const SFEM_CONSTANT_AS SMat<T, P>*)((const SFEM_CONSTANT_AS char*)
+                                                 __builtin_amdgcn_kernarg_segment_ptr() +
+                                             KA::MAT_OFF),
+        x, y);
+  } else {
+    sym_line_apply<T, P>(sm, x, y);
+  }
+}
+
+// Lane constants of one element's workgroup.
 template <int P>
 struct FacetWave {
   using L = FacetLayout<P>;
   static constexpr int TPE = P * P;
-  int lane, i, j;
+  int lane, i, j;                   // lane = thread of the element's workgroup
   bool ok;                          // lane holds a line of the element
   uint32_t own_w, mid_w, last_w;    // LDS words of the three access patterns
   template <typename T, typename M>
@@ -396,7 +462,7 @@ struct FacetWave {
   }
   __device__ __forceinline__ void init() {
     lane = threadIdx.x;
-    ok = TPE == 64 || lane < TPE;
+    ok = TPE == L::BLOCK || lane < TPE;
     const int t = ok ? lane : 0;
     i = t / P;
     j = t - i * P;
@@ -413,9 +479,14 @@ struct FacetElem {
   using L = FacetLayout<P>;
   using Mat = DMat<T, P>;
   static constexpr int LDS_WORDS = 2 * L::COPY;
-  static constexpr int MINW = GM == GEO_AFFINE ? SFEM_FACET_AFFINE_MINW : 4;
+  // P >= 9: 12 nodes per lane and several waves per element: the 256-register
+  // budget of the index-row kernels
+  static constexpr int MINW =
+      P >= 9 ? 2 : (GM == GEO_AFFINE ? SFEM_FACET_AFFINE_MINW : 4);
   static constexpr int CHAIN_MINW =
-      GM == GEO_AFFINE ? SFEM_FACET_CHAIN_MINW_AFFINE : 4;
+      P >= 9 ? 2 : (GM == GEO_AFFINE ? SFEM_FACET_CHAIN_MINW_AFFINE : 4);
+  // chain launches are compiled where they pay (operators.py: box / affine)
+  static constexpr bool CHAINS = GM == GEO_AFFINE || P <= 8;
   struct Raw { T c[GM == GEO_AFFINE ? 7 : 1]; int64_t e; };
   T cst[GM == GEO_AFFINE ? 6 : 1];
   T lw, Wm0;
@@ -469,12 +540,12 @@ struct FacetElem {
           s1[own_w + a * L::A] = ua[a];
         }
       }
-      wave_sync();
+      facet_sync<P>();
       if (lane_ok) {   // last axis, copy 1
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = s1[last_w + m];
-        line_apply<T, P, false>(dm, x, y);
+        facet_line<T, P, false, FacetParams<T>>(dm, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) s1[last_w + m] = y[m];
       }
@@ -482,14 +553,14 @@ struct FacetElem {
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = s0[mid_w + m * L::B];
-        line_apply<T, P, false>(dm, x, y);
+        facet_line<T, P, false, FacetParams<T>>(dm, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) s0[mid_w + m * L::B] = y[m];
       }
       // axis 0 in registers; w0 takes the place of d0 slice by slice
       T w0[P];
-      line_apply<T, P, false>(dm, ua, w0);
-      wave_sync();
+      facet_line<T, P, false, FacetParams<T>>(dm, ua, w0);
+      facet_sync<P>();
       if (MASS || !lane_ok) {
 #pragma unroll
         for (int a = 0; a < P; ++a) acc[a] = T(0);
@@ -541,7 +612,7 @@ struct FacetElem {
       }
       {   // transposed axis 0 at once: w0 dies here
         T dt0[P];
-        line_apply<T, P, true>(dm, w0, dt0);
+        facet_line<T, P, true, FacetParams<T>>(dm, w0, dt0);
 #pragma unroll
         for (int a = 0; a < P; ++a) {
           // lambda1 is inside lw for affine elements
@@ -550,12 +621,12 @@ struct FacetElem {
           else acc[a] = v;
         }
       }
-      wave_sync();
+      facet_sync<P>();
       if (lane_ok) {
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = s1[last_w + m];
-        line_apply<T, P, true>(dm, x, y);
+        facet_line<T, P, true, FacetParams<T>>(dm, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) s1[last_w + m] = y[m];
       }
@@ -563,11 +634,11 @@ struct FacetElem {
         T x[P], y[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = s0[mid_w + m * L::B];
-        line_apply<T, P, true>(dm, x, y);
+        facet_line<T, P, true, FacetParams<T>>(dm, x, y);
 #pragma unroll
         for (int m = 0; m < P; ++m) s0[mid_w + m * L::B] = y[m];
       }
-      wave_sync();
+      facet_sync<P>();
       if (lane_ok) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
@@ -584,7 +655,7 @@ struct FacetElem {
           acc[a] += prm.lambda0 * Wm * ua[a];
         }
       }
-      wave_sync();
+      facet_sync<P>();
     } else {
 #pragma unroll
       for (int a = 0; a < P; ++a) acc[a] = T(0);
@@ -616,8 +687,9 @@ struct BoxElem {
   static constexpr int CODE_WORDS =
       (L::COPY * 4 + (int)sizeof(T) - 1) / (int)sizeof(T);
   static constexpr int LDS_WORDS = L::COPY + CODE_WORDS;
-  static constexpr int MINW = SFEM_FACET_BOX_MINW;
-  static constexpr int CHAIN_MINW = SFEM_FACET_CHAIN_MINW_BOX;
+  static constexpr int MINW = P >= 9 ? 3 : SFEM_FACET_BOX_MINW;
+  static constexpr int CHAIN_MINW = P >= 9 ? 2 : SFEM_FACET_CHAIN_MINW_BOX;
+  static constexpr bool CHAINS = true;
   struct Raw { T c[4]; };
   T P0, P1, P2, Wm;
 
@@ -653,48 +725,48 @@ struct BoxElem {
       }
       {   // axis 0 in registers
         T r0[P];
-        sym_line_apply<T, P>(sm, ua, r0);
+        facet_sym_line<T, P, FacetParams<T>>(sm, ua, r0);
 #pragma unroll
         for (int a = 0; a < P; ++a) {
           acc[a] = P0 * r0[a];
           if (MASS) acc[a] += (Wm * ua[a]) * sym_w<T, P>(sm, a);
         }
       }
-      wave_sync();
+      facet_sync<P>();
       T y1[P];
       {
         T x[P], y2[P];
 #pragma unroll
         for (int m = 0; m < P; ++m) x[m] = lane_ok ? s0[last_w + m] : T(0);
-        sym_line_apply<T, P>(sm, x, y2);
+        facet_sym_line<T, P, FacetParams<T>>(sm, x, y2);
 #pragma unroll
         for (int m = 0; m < P; ++m)
           x[m] = lane_ok ? s0[mid_w + m * L::B] : T(0);
-        wave_sync();       // both passes have read the element
+        facet_sync<P>();       // both passes have read the element
         if (lane_ok) {
 #pragma unroll
           for (int m = 0; m < P; ++m) s0[last_w + m] = y2[m];
         }
-        sym_line_apply<T, P>(sm, x, y1);
+        facet_sym_line<T, P, FacetParams<T>>(sm, x, y1);
       }
-      wave_sync();
+      facet_sync<P>();
 #pragma unroll
       for (int a = 0; a < P; ++a) {
         const T t2 = lane_ok ? s0[own_w + a * L::A] : T(0);
         acc[a] += (P2 * t2) * sym_w<T, P>(sm, a);
       }
-      wave_sync();
+      facet_sync<P>();
       if (lane_ok) {
 #pragma unroll
         for (int m = 0; m < P; ++m) s0[mid_w + m * L::B] = y1[m];
       }
-      wave_sync();
+      facet_sync<P>();
 #pragma unroll
       for (int a = 0; a < P; ++a) {
         const T t1 = lane_ok ? s0[own_w + a * L::A] : T(0);
         acc[a] += (P1 * t1) * sym_w<T, P>(sm, a);
       }
-      wave_sync();
+      facet_sync<P>();
     } else {
 #pragma unroll
       for (int a = 0; a < P; ++a)
@@ -705,9 +777,8 @@ struct BoxElem {
 
 // One element per one-wave workgroup.  ELEM = FacetElem<..> / BoxElem<..>.
 template <typename T, int P, typename ELEM, bool SCALAR, bool OFF32>
-__global__ void __launch_bounds__(64, ELEM::MINW)
-helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
-                       FacetSlots st) {
+__global__ void __launch_bounds__(FacetLayout<P>::BLOCK, ELEM::MINW)
+helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   using L = FacetLayout<P>;
   using Mat = typename ELEM::Mat;
   using KA = FacetKernarg<FacetParams<T>, Mat>;
@@ -721,8 +792,6 @@ helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
   const int64_t e = prm.elem_list ? (int64_t)prm.elem_list[work]
                                   : (int64_t)work;
   const Mat* kdm = reinterpret_cast<const Mat*>(kernarg_bytes() + KA::MAT_OFF);
-  const FacetSlots* kst =
-      reinterpret_cast<const FacetSlots*>(kernarg_bytes() + KA::SLOT_OFF);
 
   FacetLane<P> fl;
   fl.load(prm.tab, e, w.i, w.j);
@@ -753,20 +822,22 @@ helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
       for (int a = 0; a < P; ++a) ua[a] = T(0);
     }
     el.apply(prm, dm, w, lds, ua, acc);
-    if (w.ok) {
-      uint32_t slots[3];
+    uint16_t slots[6];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) slots[q] = kst->pk[w.lane][q];
-      facet_scatter<T, P, OFF32>(fl, slots, acc, ua, og, s0, codes, w.own_w,
-                                 prm.dot_out != nullptr, udot);
-    }
-    wave_sync();
+    for (int q = 0; q < 6; ++q) slots[q] = g_facet_slots<P>.s[w.lane][q];
+    if (w.ok)
+      facet_scatter_head<T, P>(fl, acc, ua, prm.dot_out != nullptr, udot);
+    facet_scatter_tail<T, P, OFF32>(fl, slots, acc, og, s0, codes, w.own_w,
+                                    w.ok);
+    facet_sync<P>();
   }
   if (prm.dot_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
-    if (w.lane == 0)
-      unsafeAtomicAdd(&prm.dot_out[blockIdx.x & (SFEM_DOT_SLOTS - 1)], udot);
+    if ((w.lane & 63) == 0)
+      unsafeAtomicAdd(&prm.dot_out[(blockIdx.x * L::WAVES + (w.lane >> 6)) &
+                                   (SFEM_DOT_SLOTS - 1)],
+                      udot);
   }
 }
 
@@ -784,9 +855,8 @@ helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
 //     -- 34 more live registers -- measured 0.569 vs 0.580 ms at 3 waves per
 //     SIMD and 0.655 with spills at 4: not kept.)
 template <typename T, int P, typename ELEM, bool OFF32>
-__global__ void __launch_bounds__(64, ELEM::CHAIN_MINW)
-helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
-                       FacetSlots st) {
+__global__ void __launch_bounds__(FacetLayout<P>::BLOCK, ELEM::CHAIN_MINW)
+helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   using L = FacetLayout<P>;
   using Mat = typename ELEM::Mat;
   using KA = FacetKernarg<FacetParams<T>, Mat>;
@@ -808,11 +878,9 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
   const int32_t k0 = prm.chain_off[seg];
   const int32_t k1 = prm.chain_off[seg + 1];
   const Mat* kdm = reinterpret_cast<const Mat*>(kernarg_bytes() + KA::MAT_OFF);
-  const FacetSlots* kst =
-      reinterpret_cast<const FacetSlots*>(kernarg_bytes() + KA::SLOT_OFF);
-  uint32_t slots[3];
+  uint16_t slots[6];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) slots[q] = kst->pk[w.lane][q];
+  for (int q = 0; q < 6; ++q) slots[q] = g_facet_slots<P>.s[w.lane][q];
   const bool face_inner = FacetLane<P>::cls(w.i) == 1 &&
                           FacetLane<P>::cls(w.j) == 1;
   const T* ug = prm.u;
@@ -866,46 +934,52 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm,
         FacetLane<P>::issue(traw, prm.tab, (int64_t)prm.chain_elems[k + 2],
                             w.i, w.j);
     }
-    if (w.ok)
-      facet_scatter_tail<T, P, OFF32>(fe, slots, acc, og, s0, codes, w.own_w);
-    wave_sync();
+    facet_scatter_tail<T, P, OFF32>(fe, slots, acc, og, s0, codes, w.own_w,
+                                    w.ok);
+    facet_sync<P>();
   }
   }
   if (prm.dot_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
-    if (w.lane == 0)
-      unsafeAtomicAdd(&prm.dot_out[blockIdx.x & (SFEM_DOT_SLOTS - 1)], udot);
+    if ((w.lane & 63) == 0)
+      unsafeAtomicAdd(&prm.dot_out[(blockIdx.x * L::WAVES + (w.lane >> 6)) &
+                                   (SFEM_DOT_SLOTS - 1)],
+                      udot);
   }
 }
 
 // ----------------------------------------------------------------- launch ---
 template <typename T, int P, typename ELEM>
 void launch_facet_elem(const FacetParams<T>& prm, const typename ELEM::Mat& mat,
-                       const FacetSlots& slots, unsigned groups, bool off32,
-                       hipStream_t stream) {
-  const dim3 grid(groups), block(64);
+                       unsigned groups, bool off32, hipStream_t stream) {
+  const dim3 grid(groups), block(FacetLayout<P>::BLOCK);
   if (prm.chain_off) {
-    if (off32)
-      hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, true>), grid,
-                         block, 0, stream, prm, mat, slots);
-    else
-      hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, false>), grid,
-                         block, 0, stream, prm, mat, slots);
+    if constexpr (ELEM::CHAINS) {
+      if (off32)
+        hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, true>), grid,
+                           block, 0, stream, prm, mat);
+      else
+        hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, false>), grid,
+                           block, 0, stream, prm, mat);
+    } else {
+      set_error("helmholtz (facet): no chain kernel for this geometry at P=%d",
+                P);
+    }
   } else if (prm.ncomp == 1) {
     if (off32)
       hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, true, true>),
-                         grid, block, 0, stream, prm, mat, slots);
+                         grid, block, 0, stream, prm, mat);
     else
       hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, true, false>),
-                         grid, block, 0, stream, prm, mat, slots);
+                         grid, block, 0, stream, prm, mat);
   } else {
     if (off32)
       hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, false, true>),
-                         grid, block, 0, stream, prm, mat, slots);
+                         grid, block, 0, stream, prm, mat);
     else
       hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, false, false>),
-                         grid, block, 0, stream, prm, mat, slots);
+                         grid, block, 0, stream, prm, mat);
   }
 }
 
@@ -925,24 +999,23 @@ int launch_helmholtz_facet(const FacetParams<T>& prm, int geo_mode,
     set_error("helmholtz (facet): chain launches take scalar fields");
     return SFEM_EINVAL;
   }
-  static const FacetSlots slots = make_facet_slots<P>();
   const unsigned g = (unsigned)groups;
   const bool mass = prm.lambda0 != T(0);
   const bool off32 = (uint64_t)field_reals * sizeof(T) < ((uint64_t)1 << 32);
   if (geo_mode == GEO_BOX) {
     const SMat<T, P> sm = make_smat<T, P>(dmat, weights);
-    if (mass) launch_facet_elem<T, P, BoxElem<T, P, true>>(prm, sm, slots, g,
-                                                           off32, stream);
-    else launch_facet_elem<T, P, BoxElem<T, P, false>>(prm, sm, slots, g,
-                                                       off32, stream);
+    if (mass) launch_facet_elem<T, P, BoxElem<T, P, true>>(prm, sm, g, off32,
+                                                           stream);
+    else launch_facet_elem<T, P, BoxElem<T, P, false>>(prm, sm, g, off32,
+                                                       stream);
   } else {
     const DMat<T, P> dm = make_dmat<T, P>(dmat, weights, nodes);
 #define SFEM_FACET_GM(GMV)                                                    \
   do {                                                                        \
     if (mass) launch_facet_elem<T, P, FacetElem<T, P, GMV, true>>(            \
-        prm, dm, slots, g, off32, stream);                                    \
+        prm, dm, g, off32, stream);                                    \
     else launch_facet_elem<T, P, FacetElem<T, P, GMV, false>>(                \
-        prm, dm, slots, g, off32, stream);                                    \
+        prm, dm, g, off32, stream);                                    \
   } while (0)
     if (geo_mode == GEO_AFFINE) SFEM_FACET_GM(GEO_AFFINE);
     else if (geo_mode == GEO_MULTILINEAR) SFEM_FACET_GM(GEO_MULTILINEAR);
@@ -953,36 +1026,69 @@ int launch_helmholtz_facet(const FacetParams<T>& prm, int geo_mode,
   return SFEM_OK;
 }
 
-// Defined once per dtype translation unit.
+// P = 6..8 and P = 9..12 are instantiated in separate translation units per
+// dtype (compile time); sfem_helmholtz.hip picks by P.
+template <typename T>
+int dispatch_helmholtz_facet_low(const FacetParams<T>& prm, int P,
+                                 int geo_mode, int64_t groups,
+                                 int64_t field_reals, const T* dmat,
+                                 const T* weights, const T* nodes,
+                                 hipStream_t stream);
+template <typename T>
+int dispatch_helmholtz_facet_high(const FacetParams<T>& prm, int P,
+                                  int geo_mode, int64_t groups,
+                                  int64_t field_reals, const T* dmat,
+                                  const T* weights, const T* nodes,
+                                  hipStream_t stream);
+
 template <typename T>
 int dispatch_helmholtz_facet(const FacetParams<T>& prm, int P, int geo_mode,
-                             int64_t num_elements, int64_t field_reals,
+                             int64_t groups, int64_t field_reals,
                              const T* dmat, const T* weights, const T* nodes,
-                             hipStream_t stream);
+                             hipStream_t stream) {
+  if (P <= 8)
+    return dispatch_helmholtz_facet_low<T>(prm, P, geo_mode, groups,
+                                           field_reals, dmat, weights, nodes,
+                                           stream);
+  return dispatch_helmholtz_facet_high<T>(prm, P, geo_mode, groups,
+                                          field_reals, dmat, weights, nodes,
+                                          stream);
+}
 
-inline bool facet_supported_p(int P) { return P >= 6 && P <= 8; }
+inline bool facet_supported_p(int P) { return P >= 6 && P <= 12; }
 
-#define SFEM_DEFINE_FACET_DISPATCH(TYPE)                                      \
+#define SFEM_FACET_CASE(PP)                                                   \
+  case PP:                                                                    \
+    return launch_helmholtz_facet<T, PP>(prm, geo_mode, groups, field_reals,  \
+                                         dmat, weights, nodes, stream);
+
+#define SFEM_DEFINE_FACET_DISPATCH_LOW(TYPE)                                  \
   template <>                                                                 \
-  int dispatch_helmholtz_facet<TYPE>(                                         \
-      const FacetParams<TYPE>& prm, int P, int geo_mode,                      \
-      int64_t num_elements, int64_t field_reals, const TYPE* dmat,            \
-      const TYPE* weights, const TYPE* nodes, hipStream_t stream) {           \
+  int dispatch_helmholtz_facet_low<TYPE>(                                     \
+      const FacetParams<TYPE>& prm, int P, int geo_mode, int64_t groups,      \
+      int64_t field_reals, const TYPE* dmat, const TYPE* weights,             \
+      const TYPE* nodes, hipStream_t stream) {                                \
+    using T = TYPE;                                                           \
     switch (P) {                                                              \
-      case 6:                                                                 \
-        return launch_helmholtz_facet<TYPE, 6>(prm, geo_mode, num_elements,   \
-                                               field_reals, dmat, weights,    \
-                                               nodes, stream);                \
-      case 7:                                                                 \
-        return launch_helmholtz_facet<TYPE, 7>(prm, geo_mode, num_elements,   \
-                                               field_reals, dmat, weights,    \
-                                               nodes, stream);                \
-      case 8:                                                                 \
-        return launch_helmholtz_facet<TYPE, 8>(prm, geo_mode, num_elements,   \
-                                               field_reals, dmat, weights,    \
-                                               nodes, stream);                \
+      SFEM_FACET_CASE(6) SFEM_FACET_CASE(7) SFEM_FACET_CASE(8)                \
       default:                                                                \
         set_error("helmholtz (facet): P=%d outside 6..8", P);                 \
+        return SFEM_EUNSUPPORTED;                                             \
+    }                                                                         \
+  }
+
+#define SFEM_DEFINE_FACET_DISPATCH_HIGH(TYPE)                                 \
+  template <>                                                                 \
+  int dispatch_helmholtz_facet_high<TYPE>(                                    \
+      const FacetParams<TYPE>& prm, int P, int geo_mode, int64_t groups,      \
+      int64_t field_reals, const TYPE* dmat, const TYPE* weights,             \
+      const TYPE* nodes, hipStream_t stream) {                                \
+    using T = TYPE;                                                           \
+    switch (P) {                                                              \
+      SFEM_FACET_CASE(9) SFEM_FACET_CASE(10) SFEM_FACET_CASE(11)              \
+      SFEM_FACET_CASE(12)                                                     \
+      default:                                                                \
+        set_error("helmholtz (facet): P=%d outside 9..12", P);                \
         return SFEM_EUNSUPPORTED;                                             \
     }                                                                         \
   }

@@ -1,5 +1,5 @@
 // Instantiations of the facet-table Helmholtz kernels: double, P = 6..8.
 #include "sfem_helmholtz_facet.h"
 namespace sfem {
-SFEM_DEFINE_FACET_DISPATCH(double)
+SFEM_DEFINE_FACET_DISPATCH_LOW(double)
 }  // namespace sfem

@@ -285,6 +285,18 @@ def test_config4_taylor_green_on_periodic_blocks(monkeypatch, grid):
 
   kv, uv = table(sem_g.velocity.mesh.node_coords, u_g)
   kp, pv = table(sem_g.pressure.pspace.mesh.node_coords, p_g)
+  # ... and the ORACLE's run of that box (same premesh, same node numbering):
+  # the rank-assembled fields are compared with both
+  from swirl_fem_amd.common.premesh_commons import box_mesh
+  from tests.test_gpu_stokes import _taylor_green_oracle
+  pm_g = box_mesh(tuple(n * g for g in grid), (0.0,) * 3, (two_pi,) * 3,
+                  periodic_dims=(0, 1, 2))
+  uo, po = _taylor_green_oracle(pm_g, order, kw['reynolds'], kw['dt'], steps,
+                                kw['time_order'], kw['tol'])
+  _, uov = table(sem_g.velocity.mesh.node_coords,
+                 torch.as_tensor(uo, device=DEV))
+  _, pov = table(sem_g.pressure.pspace.mesh.node_coords,
+                 torch.as_tensor(po, device=DEV))
 
   def rank_main(rank):
     sem, u, p, diag = drv.taylor_green_blocks(n=n, block_grid=grid,
@@ -296,11 +308,14 @@ def test_config4_taylor_green_on_periodic_blocks(monkeypatch, grid):
         device=DEV)
     return (float((u - uv[iu]).abs().max() / uv.abs().max()),
             float((p - pv[ip]).abs().max() / pv.abs().max()),
-            diag['kinetic_energy'], diag['cg_iterations'])
+            diag['kinetic_energy'], diag['cg_iterations'],
+            float((u - uov[iu]).abs().max() / uov.abs().max()),
+            float((p - pov[ip]).abs().max() / max(1.0, float(pov.abs().max()))))
 
   results = _run_ranks(mail, rank_main)
   for r in range(mail.world):
-    eu, ep, energy, iters = results[r]
+    eu, ep, energy, iters, eu_orc, ep_orc = results[r]
     assert eu < 1e-8 and ep < 1e-6, results[r][:2]
+    assert eu_orc < 1e-8 and ep_orc < 1e-6, results[r][4:]   # vs the oracle
     assert iters == results[0][3]
     np.testing.assert_allclose(energy, diag_g['kinetic_energy'], rtol=1e-9)

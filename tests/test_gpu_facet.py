@@ -1,6 +1,6 @@
 """GPU parity of the compact-connectivity (facet table) Helmholtz kernels
 (`csrc/sfem_helmholtz_facet.h`): table builder vs the index rows it replaces,
-operator vs the CPU oracle and vs the index-row kernels, 3D, P = 6..8.
+operator vs the CPU oracle and vs the index-row kernels, 3D, P = 6..12.
 
 fp64 tolerance 1e-10 relative, fp32 3e-5 (BASELINE.json north_star: 1e-10 /
 1e-5 with the fp32 margin the other fused-kernel tests use).
@@ -90,7 +90,7 @@ def table_ids(tab, P):
   return ids.reshape(E, -1), flags.reshape(E, -1)
 
 
-@pytest.mark.parametrize('P', [3, 4, 6, 7, 8, 12])
+@pytest.mark.parametrize('P', [3, 4, 6, 7, 8, 9, 12])
 def test_facet_table_reproduces_the_index_rows(P):
   rng = np.random.default_rng(P)
   n = 2 if P > 8 else 3
@@ -127,19 +127,26 @@ def test_facet_table_reproduces_the_index_rows(P):
     assert ok2[rest].all()
 
 
-@pytest.mark.parametrize('P', [6, 7, 8])
+@pytest.mark.parametrize('P,chain', [
+    (6, '16'), (6, '3'), (6, 'off'), (7, '16'), (7, '3'), (7, 'off'),
+    (8, '16'), (8, '3'), (8, 'off'),
+    # several waves per element
+    (9, '16'), (10, 'off'), (11, '3'), (12, '16'), (12, 'off')])
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
-@pytest.mark.parametrize('chain', ['16', '3', 'off'])
 def test_facet_helmholtz_matches_oracle(P, dtype, chain, monkeypatch):
   """`chain`: scalar fields walk chains of elements (segments of <= 16 / 3
-  elements, the shared face carried in registers) or one element per wave."""
+  elements, the shared face carried in registers) or one element per wave
+  (P <= 8) / workgroup (P >= 9)."""
   tol = TOL[dtype]
   if chain == 'off':
     monkeypatch.setenv('SFEM_CHAIN', '0')
   else:
     monkeypatch.setenv('SFEM_CHAIN_LEN', chain)
-  for mode, rotate in (('structured', False), ('stretched', True),
-                       ('sheared', True), ('jittered', True)):
+  modes = (('structured', False), ('stretched', True), ('sheared', True),
+           ('jittered', True))
+  if P >= 9:          # the oracle's dense element matrices grow as P^6
+    modes = (('structured', False), ('sheared', True), ('jittered', True))
+  for mode, rotate in modes:
     rng = np.random.default_rng(100 * P + len(mode))
     rp = make_mesh(3 if chain == '3' and P == 6 else 2, P, mode, rng, rotate)
     mesh = rp.finalize(device=DEV, dtype=dtype)
@@ -156,12 +163,18 @@ def test_facet_helmholtz_matches_oracle(P, dtype, chain, monkeypatch):
     assert plain.facet_parts is None
     for g, op in ops.items():
       assert op.facet_parts is not None, (mode, g)
-      assert all('facet_table' in p for p in op.facet_parts), (mode, g)
+      # (multilinear elements of P >= 9 keep their index rows)
+      rows_ok = P >= 9 and (g == 'multilinear' or mode == 'jittered') and \
+          g != 'stored'
+      assert all(('facet_table' in p) != rows_ok
+                 for p in op.facet_parts), (mode, g)
       chained = [p for p in op.facet_parts if 'chains' in p]
       light = [p for p in op.facet_parts
                if p['geo_mode'] in (_lib.GEO_BOX, _lib.GEO_AFFINE)]
-      assert len(chained) == len(light), (mode, g)
-      if chain == 'off' or not chained:
+      assert len(chained) == (len(light) if P <= 8 else 0), (mode, g)
+      if rows_ok:
+        assert 'helmholtz_kernel' in op.kernel_name()
+      elif chain == 'off' or not chained:
         assert 'helmholtz_facet_kernel' in op.kernel_name()
       else:
         assert 'helmholtz_chain_kernel' in op.kernel_name()

@@ -215,6 +215,49 @@ def test_taylor_green_3d_periodic():
   assert relerr(sem.E(dev(q), 1e-2, 3), orc.E(q, 1e-2, 3)) < 1e-9
 
 
+def _taylor_green_oracle(pm, order, reynolds, dt, steps, time_order, tol):
+  """The driver's Taylor-Green run restated with the oracle (dense Kronecker
+  element matrices, un-fused CG): (u, p) after `steps` steps."""
+  v, pp = _staged(pm, order)
+  orc = O.StokesOracle(v, pp, order, np.zeros(len(v['node_coords']), bool))
+  x = v['node_coords']
+  u0 = np.stack([np.sin(x[:, 0]) * np.cos(x[:, 1]) * np.cos(x[:, 2]),
+                 -np.cos(x[:, 0]) * np.sin(x[:, 1]) * np.cos(x[:, 2]),
+                 np.zeros(len(x))], axis=-1)
+  us = (u0,) * time_order
+  ps = (np.zeros(len(pp['node_coords'])),) * time_order
+  Cus = (orc.C(u0),) * time_order
+  for _ in range(steps):
+    uo, po, Co, _ = O.navier_stokes_step(orc, us, ps, Cus, reynolds, dt,
+                                         time_order, tol=tol, atol=0.0)
+    us, ps, Cus = us[1:] + (uo,), ps[1:] + (po,), Cus[1:] + (Co,)
+  return us[-1], ps[-1]
+
+
+def test_taylor_green_3d_p7_step_matches_oracle():
+  """BASELINE config 4's workload at ITS order: 3D Taylor-Green vortex, p = 7
+  velocity / Gauss pressure on 6^3 points, triply periodic 2^3 box, Re = 1600,
+  BDF3 / EXT2, over-integrated convection on 10^3 points -- two full
+  `navier_stokes_step`s (navier_stokes.py:350-458, datagen.py:90-102) against
+  the oracle's.  At this order every fused kernel of the step is the
+  instantiation config 4 runs (facet / chain Helmholtz at P = 8, D and D^T
+  with a P = 6 pressure space, the two-grid convection)."""
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.examples import navier_stokes_driver as drv
+  n, order, steps = 2, 7, 2
+  kw = dict(reynolds=1600.0, dt=1e-3, steps=steps, time_order=3)
+  sem, u, p, diag = drv.taylor_green(n=n, order=order, device=DEV, tol=1e-12,
+                                     **kw)
+  pm = unit_cube_mesh(n, ndim=3, a=0.0, b=2 * np.pi, periodic_dims=(0, 1, 2))
+  uo, po = _taylor_green_oracle(pm, order, tol=1e-12, **kw)
+  assert relerr(u, uo) < 1e-8
+  pg = p.cpu().numpy()
+  assert np.abs(pg - po).max() < 1e-7 * max(1.0, np.abs(po).max())
+  assert diag['max_divergence'] < 1e-6
+  e = diag['kinetic_energy']
+  assert e[-1] < e[0]
+
+
 def test_config3_unstructured_fixture():
   """BASELINE config 3 in miniature: 4 x 4 quads, vertices
   jittered by +-0.2 h, random element order and random local orientations,
