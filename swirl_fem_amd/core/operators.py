@@ -185,7 +185,8 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
       # kernels have no registers left for the look-ahead (measured slower)
       # ... and elements that span several waves (P >= 9: the chain kernels
       # run at 2 waves per SIMD there; p = 11 fp32 box 1.74 vs 1.46 ms)
-      if seg_len > 1 and mode in (_GEO_BOX, _GEO_AFFINE) and P <= 8:
+      if seg_len > 1 and mode in (_GEO_BOX, _GEO_AFFINE) and (
+          P <= 8 or os.environ.get('SFEM_CHAIN_HI') == '1'):
         new['chains'] = facet_chains(mesh.elements, ids, P, seg_len)
         new['chain_len'] = seg_len
     out.append(new)

@@ -401,6 +401,12 @@ __device__ __forceinline__ const char* kernarg_bytes() {
 #ifndef SFEM_FACET_BOX_MINW
 #define SFEM_FACET_BOX_MINW 5
 #endif
+#ifndef SFEM_FACET_BOX_MINW_HI
+#define SFEM_FACET_BOX_MINW_HI 3
+#endif
+#ifndef SFEM_FACET_CHAIN_MINW_HI
+#define SFEM_FACET_CHAIN_MINW_HI 2
+#endif
 #ifndef SFEM_FACET_CHAIN_MINW_BOX
 #define SFEM_FACET_CHAIN_MINW_BOX 4
 #endif
@@ -687,8 +693,9 @@ struct BoxElem {
   static constexpr int CODE_WORDS =
       (L::COPY * 4 + (int)sizeof(T) - 1) / (int)sizeof(T);
   static constexpr int LDS_WORDS = L::COPY + CODE_WORDS;
-  static constexpr int MINW = P >= 9 ? 3 : SFEM_FACET_BOX_MINW;
-  static constexpr int CHAIN_MINW = P >= 9 ? 2 : SFEM_FACET_CHAIN_MINW_BOX;
+  static constexpr int MINW = P >= 9 ? SFEM_FACET_BOX_MINW_HI : SFEM_FACET_BOX_MINW;
+  static constexpr int CHAIN_MINW =
+      P >= 9 ? SFEM_FACET_CHAIN_MINW_HI : SFEM_FACET_CHAIN_MINW_BOX;
   static constexpr bool CHAINS = true;
   struct Raw { T c[4]; };
   T P0, P1, P2, Wm;
