@@ -180,13 +180,11 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
       new.pop('shared_order', None)
       new['facet_table'] = tab
       new['geo_const'] = cst
-      # chains pay where the element arithmetic is light (box / affine:
-      # 0.72 -> 0.58 / 0.66 ms at config 2); the multilinear and stored-factor
-      # kernels have no registers left for the look-ahead (measured slower)
-      # ... and elements that span several waves (P >= 9: the chain kernels
-      # run at 2 waves per SIMD there; p = 11 fp32 box 1.74 vs 1.46 ms)
-      if seg_len > 1 and mode in (_GEO_BOX, _GEO_AFFINE) and (
-          P <= 8 or os.environ.get('SFEM_CHAIN_HI') == '1'):
+      # chains (one-wave elements): box 0.72 -> 0.58 ms, affine 0.72 -> 0.66,
+      # multilinear 0.92 -> 0.87, stored 1.86 -> 1.80 at config 2; elements
+      # that span several waves (P >= 9) lose with them (p = 11 fp32 box 1.74
+      # vs 1.46 ms)
+      if seg_len > 1 and (P <= 8 or os.environ.get('SFEM_CHAIN_HI') == '1'):
         new['chains'] = facet_chains(mesh.elements, ids, P, seg_len)
         new['chain_len'] = seg_len
     out.append(new)

@@ -41,6 +41,8 @@
 //   * No per-slot predicates: one element per workgroup, the grid is exactly
 //     the element list, tables hold no padding slots.
 #pragma once
+#include <stdlib.h>
+
 #include "sfem_helmholtz.h"
 
 namespace sfem {
@@ -407,6 +409,12 @@ __device__ __forceinline__ const char* kernarg_bytes() {
 #ifndef SFEM_FACET_CHAIN_MINW_HI
 #define SFEM_FACET_CHAIN_MINW_HI 2
 #endif
+// multilinear / stored factors: the look-ahead of the chain loop needs a 168-
+// register budget (at 4 waves per SIMD: 116-144 B of spills, 1.28 ms; at 3:
+// multilinear 0.865 vs 0.919 ms one element per wave, stored 1.795 vs 1.855)
+#ifndef SFEM_FACET_CHAIN_MINW_GEN
+#define SFEM_FACET_CHAIN_MINW_GEN 3
+#endif
 #ifndef SFEM_FACET_CHAIN_MINW_BOX
 #define SFEM_FACET_CHAIN_MINW_BOX 4
 #endif
@@ -490,7 +498,8 @@ struct FacetElem {
   static constexpr int MINW =
       P >= 9 ? 2 : (GM == GEO_AFFINE ? SFEM_FACET_AFFINE_MINW : 4);
   static constexpr int CHAIN_MINW =
-      P >= 9 ? 2 : (GM == GEO_AFFINE ? SFEM_FACET_CHAIN_MINW_AFFINE : 4);
+      P >= 9 ? 2 : (GM == GEO_AFFINE ? SFEM_FACET_CHAIN_MINW_AFFINE
+                                    : SFEM_FACET_CHAIN_MINW_GEN);
   // chain launches are compiled where they pay (operators.py: box / affine)
   static constexpr bool CHAINS = GM == GEO_AFFINE || P <= 8;
   struct Raw { T c[GM == GEO_AFFINE ? 7 : 1]; int64_t e; };
@@ -1008,7 +1017,11 @@ int launch_helmholtz_facet(const FacetParams<T>& prm, int geo_mode,
   }
   const unsigned g = (unsigned)groups;
   const bool mass = prm.lambda0 != T(0);
-  const bool off32 = (uint64_t)field_reals * sizeof(T) < ((uint64_t)1 << 32);
+  // fields of 4 GiB and more take the 64-bit addressing instantiations
+  // (SFEM_FACET_OFF64=1 forces them: tests)
+  const char* force64 = getenv("SFEM_FACET_OFF64");
+  const bool off32 = (uint64_t)field_reals * sizeof(T) < ((uint64_t)1 << 32) &&
+                     !(force64 && force64[0] == '1');
   if (geo_mode == GEO_BOX) {
     const SMat<T, P> sm = make_smat<T, P>(dmat, weights);
     if (mass) launch_facet_elem<T, P, BoxElem<T, P, true>>(prm, sm, g, off32,
