@@ -12,7 +12,10 @@ import bench
 tag = sys.argv[1]
 rnd = tag[:3]
 out = os.path.join(ROOT, 'profiles'); src = os.path.join(ROOT, 'gpurun_out')
-src_hash = bench.kernel_source_hash()
+try:      # written on the GPU box by gpu_round3.sh: the sources that were measured
+  src_hash = open(os.path.join(src, f'src_hash_{tag}.txt')).read().strip()
+except OSError:
+  src_hash = bench.kernel_source_hash()
 
 
 def one(pattern):

@@ -47,4 +47,7 @@ for w in $WHAT; do
   esac
 done
 find $O -name "*kernel_trace.csv" -size +2M -delete
+# the sources this run measured (profiles/ does not travel back from the GPU
+# box: run scripts/collect_profiles3.py $TAG again where gpurun_out/ is merged)
+( cd $R && python3 -c "import bench; print(bench.kernel_source_hash())" ) > $O/src_hash_$TAG.txt
 python3 $R/scripts/collect_profiles3.py $TAG
