@@ -393,6 +393,15 @@ typedef struct sfem_stokes_args {
   double* dot_out;        /* div: NULL, or SFEM_DOT_SLOTS device doubles that    */
                           /*   accumulate partial sums of p_in . p_out (the p.Ap */
                           /*   of the pressure CG when p_in is its direction)    */
+  /* div / grad_t, 3D, P = 6..8, node_stride = 1 (component-major fields):    */
+  /* compact connectivity of the velocity mesh and its chains, exactly as in  */
+  /* sfem_helmholtz_args (NULL = off; `enc` / `shared_order` are then not     */
+  /* read).  Both are needed: a launch without chains passes segments of one  */
+  /* element.  The segments must hold every element of the launch once.       */
+  const int32_t* facet_table;     /* (E, 27, 4) from sfem_facet_table_build   */
+  const int32_t* chain_offsets;   /* (num_chains + 1,)                        */
+  const int32_t* chain_elems;
+  int64_t num_chains;
 } sfem_stokes_args;
 
 int sfem_stokes_setup(const void* invjac, const void* jacdet,

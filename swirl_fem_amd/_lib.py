@@ -58,6 +58,8 @@ class StokesArgs(ctypes.Structure):
       ('node_stride', c_i64), ('comp_stride', c_i64),
       ('scale_per_node', c_i32), ('shared_order', c_ptr),
       ('shared_stride', c_i32), ('dot_out', c_ptr),
+      ('facet_table', c_ptr), ('chain_offsets', c_ptr), ('chain_elems', c_ptr),
+      ('num_chains', c_i64),
   ]
 
 

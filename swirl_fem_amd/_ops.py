@@ -557,6 +557,12 @@ def _stokes_args(vec, enc, penc, part, host, ndim, P, zero_range,
   if not vec.is_contiguous():
     node_stride, comp_stride = 1, vec.stride(-1)
   lst = part.get('elem_list')
+  ft = part.get('facet_table')
+  ch = part.get('chains') if ft is not None else None
+  if ft is not None:
+    ptrs = dict(ptrs, facet_table=_dptr(ft), chain_offsets=_dptr(ch[0]),
+                chain_elems=_dptr(ch[1]), num_chains=ch[0].numel() - 1)
+    shared_order = None
   return _lib.StokesArgs(
       enc=_dptr(enc), penc=_dptr(penc), kfac=_dptr(part.get('kfac')),
       geo_elem=_dptr(part.get('geo_elem')),

@@ -94,6 +94,7 @@ def classify_geometry(fespace):
 
 _GEO_POINT, _GEO_AFFINE, _GEO_MULTILINEAR, _GEO_BOX = 0, 1, 3, 5
 FACET_P = tuple(range(6, 13))  # orders the facet-table kernels are compiled for
+STOKES_FACET_P = (6, 7, 8)     # ... and the facet-table Stokes kernels
 BOX_TOL = {torch.float64: 1e-13, torch.float32: 5e-7}
 
 
@@ -612,6 +613,9 @@ class StokesDivGrad:
   dirichlet_u8: torch.Tensor | None = None
   shared_order: torch.Tensor | None = None   # see `shared_slot_order`
   _split: tuple | None = None
+  # the launches on compact connectivity + chains (component-major fields,
+  # 3D, P = 6..8: `csrc/sfem_stokes_facet.h`), or None
+  facet_parts: list | None = None
 
   @classmethod
   def create(cls, vspace, pspace, dirichlet_mask=None,
@@ -668,10 +672,51 @@ class StokesDivGrad:
             'weights': np.asarray(vspace.quadrature.weights),
             'nodes': np.asarray(mesh.gridpoints_1d.node_values),
             'interp': pspace.interpolator._interpolation_matrix_1d()}
+    facet_parts = None
+    if (mesh.ndim == 3 and mesh.gridpoints_1d.num_points in STOKES_FACET_P and
+        os.environ.get('SFEM_FACET', '1') != '0' and
+        os.environ.get('SFEM_STOKES_FACET', '1') != '0'):
+      facet_parts = cls._facet_parts(mesh, parts, mask, plan.multiplicity)
     return cls(vspace=vspace, pspace=pspace, parts=parts, enc=enc, penc=penc,
                host=host, zero_range=plan.zero_range,
                num_pressure_nodes=pspace.mesh.num_nodes, dirichlet_u8=mask,
-               shared_order=cls._order(mesh, enc))
+               shared_order=cls._order(mesh, enc), facet_parts=facet_parts)
+
+  @staticmethod
+  def _facet_parts(mesh, parts, mask, multiplicity):
+    """`parts` on the velocity mesh's facet table, every launch a list of chain
+    segments (`facet_chains`); elements the table builder refuses keep their
+    index rows.  None if no element qualifies."""
+    E = mesh.num_elements
+    P = mesh.gridpoints_1d.num_points
+    tab, ok = _ops.facet_table(mesh.elements, mask, multiplicity, P)
+    if not bool(ok.any()):
+      return None
+    seg_len = max(1, int(os.environ.get('SFEM_CHAIN_LEN', '8')))
+    if os.environ.get('SFEM_CHAIN', '1') == '0':
+      seg_len = 1
+    every = torch.arange(E, device=ok.device)
+    out = []
+    for part in parts:
+      ids = every if 'elem_list' not in part else part['elem_list'].long()
+      good = ok[ids]
+      for sel, facet in ((ids[good], True), (ids[~good], False)):
+        if sel.numel() == 0:
+          continue
+        new = {k: v for k, v in part.items() if k != 'elem_list'}
+        if sel.numel() < E:
+          new['elem_list'] = sel.to(torch.int32).contiguous()
+        if facet:
+          new['facet_table'] = tab
+          new['chains'] = facet_chains(mesh.elements, sel, P, seg_len)
+        out.append(new)
+    return out
+
+  def _parts_for(self, field):
+    """Facet / chain launches for component-major fields."""
+    if self.facet_parts is not None and _ops.is_component_major(field):
+      return self.facet_parts
+    return self.parts
 
   @staticmethod
   def _order(mesh, enc):
@@ -757,9 +802,9 @@ class StokesDivGrad:
       dot_with = dot_with.to(u.dtype).contiguous()
       if tuple(dot_with.shape) != (self.num_pressure_nodes,):
         raise ValueError('dot_with must be a pressure vector')
-    return _ops.stokes_div(u, out, self.enc, self.penc, self.parts, self.host,
-                           mesh.ndim, mesh.gridpoints_1d.num_points, scale,
-                           dot_with, dot_out)
+    return _ops.stokes_div(u, out, self.enc, self.penc, self._parts_for(u),
+                           self.host, mesh.ndim, mesh.gridpoints_1d.num_points,
+                           scale, dot_with, dot_out)
 
   def grad_t(self, p, out=None, component_major=False, scale=None):
     """(Np,) -> (N, d):  mask * (scale * D^T p), the factor applied to every
@@ -781,8 +826,8 @@ class StokesDivGrad:
       scale = scale.to(p.dtype)
       scale = (scale.contiguous() if scale.dim() == 1
                else _like_layout(scale.expand_as(out), out))
-    return _ops.stokes_grad_t(p, out, self.enc, self.penc, self.parts,
-                              self.host, mesh.ndim,
+    return _ops.stokes_grad_t(p, out, self.enc, self.penc,
+                              self._parts_for(out), self.host, mesh.ndim,
                               mesh.gridpoints_1d.num_points, self.zero_range,
                               self.shared_order, scale)
 

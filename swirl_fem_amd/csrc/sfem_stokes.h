@@ -83,6 +83,33 @@ __device__ __forceinline__ void interp_t(const IMat<T, P, PP>& im,
   }
 }
 
+// The same two products with the matrix re-read from the kernarg segment per
+// product (scalar loads): 48 entries at P = 8 fp64 are 96 SGPRs otherwise.
+template <typename T, int P, int PP>
+__device__ __forceinline__ void interp_fwd_mem(
+    const SFEM_CONSTANT_AS IMat<T, P, PP>* km, const T (&x)[PP], T (&y)[P]) {
+  asm volatile("" : "+s"(km));
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < PP; ++k) s += km->m[q * PP + k] * x[k];
+    y[q] = s;
+  }
+}
+template <typename T, int P, int PP>
+__device__ __forceinline__ void interp_t_mem(
+    const SFEM_CONSTANT_AS IMat<T, P, PP>* km, const T (&x)[P], T (&y)[PP]) {
+  asm volatile("" : "+s"(km));
+#pragma unroll
+  for (int k = 0; k < PP; ++k) {
+    T s = T(0);
+#pragma unroll
+    for (int q = 0; q < P; ++q) s += km->m[q * PP + k] * x[q];
+    y[k] = s;
+  }
+}
+
 // Per-lane cofactor state of one element:  Kw[a][c] = w_q detJ d xi_a / d x_c.
 template <typename T, int P, int DIM, int GM>
 struct ElemCof {
@@ -158,9 +185,56 @@ struct ElemCof {
     }
   }
 
+  // The same for a lane that already holds its in-plane weight and node
+  // coordinates (3D; kernels that visit many elements per wave).
+  __device__ __forceinline__ void init_lane(const StokesParams<T>& prm,
+                                            int64_t e, int t, T wbc_, T s,
+                                            T tt) {
+    int64_t slot = e;
+    if (HAS_POINT && prm.geo_index) slot = prm.geo_index[e];
+    base = reinterpret_cast<const char*>(prm.kfac) +
+           (HAS_POINT ? slot * (int64_t)(DIM * DIM) * NPT * sizeof(T) : 0);
+    lane_off = (uint32_t)(t * sizeof(T));
+    wbc = wbc_;
+    if (HAS_POINT) return;
+    const T* A = prm.geo_elem + e * 24;
+    T a0[3], a1[3], a2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const T A1 = A[c], A2 = A[3 + c], A3 = A[6 + c], A4 = A[9 + c],
+              A5 = A[12 + c], A6 = A[15 + c], A7 = A[18 + c];
+      a0[c] = A1 + A4 * s + (A6 + A7 * s) * tt;
+      a1[c] = A2 + A5 * tt;
+      a2[c] = A3 + A5 * s;
+      if (HAS_MULTI) {
+        r0[c] = a0[c];
+        p1[c] = a1[c];
+        q1[c] = A4 + A7 * tt;
+        p2[c] = a2[c];
+        q2[c] = A6 + A7 * s;
+      }
+    }
+    if (HAS_AFFINE) {
+      kc[0] = a1[1] * a2[2] - a1[2] * a2[1];
+      kc[1] = a1[2] * a2[0] - a1[0] * a2[2];
+      kc[2] = a1[0] * a2[1] - a1[1] * a2[0];
+      kc[3] = a2[1] * a0[2] - a2[2] * a0[1];
+      kc[4] = a2[2] * a0[0] - a2[0] * a0[2];
+      kc[5] = a2[0] * a0[1] - a2[1] * a0[0];
+      kc[6] = a0[1] * a1[2] - a0[2] * a1[1];
+      kc[7] = a0[2] * a1[0] - a0[0] * a1[2];
+      kc[8] = a0[0] * a1[1] - a0[1] * a1[0];
+    }
+  }
+
   // K[a' * DIM + c] at the lane's node of slice a, times the quadrature weight
   __device__ __forceinline__ void cof(const DMat<T, P>& dm, int a,
                                       T (&K)[DIM * DIM]) const {
+    cof_wx(dm.w[a], dm.x[a], a, K);
+  }
+  // ... with the 1D weight and node value of slice a handed in
+  __device__ __forceinline__ void cof_wx(T w_a, T x_a, int a,
+                                         T (&K)[DIM * DIM]) const {
     if (HAS_POINT) {
 #pragma unroll
       for (int f = 0; f < DIM * DIM; ++f)
@@ -169,13 +243,13 @@ struct ElemCof {
                     (uint32_t)(a * TPE * sizeof(T))));
       return;
     }
-    const T wq = wbc * dm.w[a];
+    const T wq = wbc * w_a;
     if (HAS_AFFINE) {
 #pragma unroll
       for (int f = 0; f < DIM * DIM; ++f) K[f] = wq * kc[f];
       return;
     }
-    const T r = dm.x[a];
+    const T r = x_a;
     if (DIM == 3) {
       T R1[3], R2[3];
 #pragma unroll

@@ -1,6 +1,6 @@
 // libsfem_hip: C-ABI entry points of the fused Stokes divergence (D) and
 // pressure-gradient (D^T) operators plus their setup kernel.
-#include "sfem_stokes.h"
+#include "sfem_stokes_facet.h"
 
 namespace sfem {
 
@@ -51,6 +51,15 @@ static int run_stokes(const sfem_stokes_args* a, int mode,
   prm.shared_order = a->shared_order;
   prm.shared_stride = a->shared_stride;
   prm.dot_out = mode == 0 ? a->dot_out : nullptr;
+  if (a->facet_table && (mode == 0 || mode == 1)) {
+    StokesFacetParams<T> fprm{};
+    fprm.base = prm;
+    fprm.tab = a->facet_table;
+    fprm.chain_off = a->chain_offsets;
+    fprm.chain_elems = a->chain_elems;
+    return dispatch_stokes_facet<T>(fprm, a->P, mode, a->num_chains,
+                                    a->num_nodes, stream);
+  }
   if (a->ndim == 3) return dispatch_stokes<T, 3>(prm, a->P, mode, stream);
   return dispatch_stokes<T, 2>(prm, a->P, mode, stream);
 }
@@ -80,6 +89,15 @@ static int check_stokes(const char* who, const sfem_stokes_args* a) {
   if (a->elem_list)
     SFEM_REQUIRE(a->num_listed >= 0 && a->num_listed <= a->num_elements,
                  "%s: bad element list length", who);
+  if (a->facet_table) {
+    SFEM_REQUIRE(a->ndim == 3 && stokes_facet_supported_p(a->P),
+                 "%s: facet tables are 3D, P = 6..8", who);
+    SFEM_REQUIRE(a->node_stride == 1,
+                 "%s: facet tables need component-major fields "
+                 "(node_stride = 1)", who);
+    SFEM_REQUIRE(a->chain_offsets && a->chain_elems && a->num_chains > 0,
+                 "%s: facet tables need the chain lists", who);
+  }
   return SFEM_OK;
 }
 
@@ -129,7 +147,8 @@ int sfem_stokes_convect_local(const sfem_stokes_args* a, sfem_stream_t stream) {
 int sfem_stokes_div(const sfem_stokes_args* a, sfem_stream_t stream) {
   int rc = check_stokes("sfem_stokes_div", a);
   if (rc) return rc;
-  SFEM_REQUIRE(a->enc && a->interp, "sfem_stokes_div: null pointer");
+  SFEM_REQUIRE((a->enc || a->facet_table) && a->interp,
+               "sfem_stokes_div: null pointer");
   const int64_t work = a->elem_list ? a->num_listed : a->num_elements;
   if (work == 0) return SFEM_OK;
   SFEM_REQUIRE(a->u && a->p_out, "sfem_stokes_div: null pointer");
@@ -157,7 +176,8 @@ static int zero_shared_range(const sfem_stokes_args* a, sfem_stream_t stream) {
 int sfem_stokes_grad_t(const sfem_stokes_args* a, sfem_stream_t stream) {
   int rc = check_stokes("sfem_stokes_grad_t", a);
   if (rc) return rc;
-  SFEM_REQUIRE(a->num_elements == 0 || (a->enc && a->interp),
+  SFEM_REQUIRE(a->num_elements == 0 ||
+                   ((a->enc || a->facet_table) && a->interp),
                "sfem_stokes_grad_t: null pointer");
   SFEM_REQUIRE(a->zero_begin >= 0 && a->zero_end >= a->zero_begin &&
                    a->zero_end <= a->num_nodes,

