@@ -98,6 +98,18 @@ STOKES_FACET_P = (6, 7, 8)     # ... and the facet-table Stokes kernels
 BOX_TOL = {torch.float64: 1e-13, torch.float32: 5e-7}
 
 
+def chain_segment_length(num_elements):
+  """Elements per chain segment (= per workgroup of a chain launch): 8 on
+  large meshes; shorter when that would leave the 256 CUs x 16 waves of an
+  MI355X with fewer than ~4 rounds of workgroups (16^3 elements in chains of
+  8 are 512 workgroups: the Taylor-Green step at 16^3 went from 33 to 50 ms).
+  `SFEM_CHAIN_LEN` overrides."""
+  env = os.environ.get('SFEM_CHAIN_LEN')
+  if env:
+    return max(1, int(env))
+  return max(1, min(8, num_elements // 16384))
+
+
 def facet_chains(elements, ids, P, seg_len):
   """Walks the elements `ids` (int64, device) as chains for the chain launches
   of the facet kernels (`sfem_helmholtz_args.chain_offsets`): element y follows
@@ -168,7 +180,7 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
   cst = None
   out = []
   P = mesh.gridpoints_1d.num_points
-  seg_len = int(os.environ.get('SFEM_CHAIN_LEN', '8'))
+  seg_len = chain_segment_length(E)
 
   def add(part, ids, mode, facet):
     if ids.numel() == 0:
@@ -692,7 +704,7 @@ class StokesDivGrad:
     tab, ok = _ops.facet_table(mesh.elements, mask, multiplicity, P)
     if not bool(ok.any()):
       return None
-    seg_len = max(1, int(os.environ.get('SFEM_CHAIN_LEN', '8')))
+    seg_len = chain_segment_length(E)
     if os.environ.get('SFEM_CHAIN', '1') == '0':
       seg_len = 1
     every = torch.arange(E, device=ok.device)

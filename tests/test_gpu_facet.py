@@ -140,6 +140,7 @@ def test_facet_helmholtz_matches_oracle(P, dtype, chain, monkeypatch):
   tol = TOL[dtype]
   if chain == 'off':
     monkeypatch.setenv('SFEM_CHAIN', '0')
+    monkeypatch.setenv('SFEM_CHAIN_LEN', '8')    # built, not used
   else:
     monkeypatch.setenv('SFEM_CHAIN_LEN', chain)
   modes = (('structured', False), ('stretched', True), ('sheared', True),
@@ -274,3 +275,15 @@ def test_facet_kernels_with_64_bit_addressing(P, monkeypatch):
         ud = dev(uu, dtype) if nc == 1 else dev(u.T.copy(), dtype).t()
         got = op.apply(ud, 0.4, 1.2)
         assert relerr(got, reference(ofes, uu, 0.4, 1.2, mk)) < TOL[dtype]
+
+
+def test_chain_segments_follow_the_mesh_size(monkeypatch):
+  """Small meshes get short (or no) chains, so that a launch still fills the
+  chip: 8 elements per workgroup only from 131 072 elements on."""
+  from swirl_fem_amd.core import operators
+  monkeypatch.delenv('SFEM_CHAIN_LEN', raising=False)
+  assert operators.chain_segment_length(16 ** 3) == 1
+  assert operators.chain_segment_length(32 ** 3) == 2
+  assert operators.chain_segment_length(64 ** 3) == 8
+  monkeypatch.setenv('SFEM_CHAIN_LEN', '5')
+  assert operators.chain_segment_length(16 ** 3) == 5
