@@ -158,6 +158,7 @@ stokes_grad_t_chain_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
   const T lane_w = kdm->w[w.i] * kdm->w[w.j];
   const T lane_s = kdm->x[w.i], lane_t = kdm->x[w.j];
   const bool has_scale = prm.scale != nullptr;
+  const bool scale_node = has_scale && prm.scale_comp_stride == 0;
 
   FacetLane<P> fl, fn;
   typename FacetLane<P>::Raw traw;
@@ -172,6 +173,15 @@ stokes_grad_t_chain_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
     const int64_t e = (int64_t)fprm.chain_elems[k];
     ElemCof<T, P, 3, GM> geom;
     geom.init_lane(prm, e, w.ok ? w.lane : 0, lane_w, lane_s, lane_t);
+    // one factor per node (scale_comp_stride = 0, the lumped-mass Q of E):
+    // gathered once per element, behind the pressure interpolation
+    T sc[P];
+    if (scale_node) {
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+        sc[a] = w.ok ? *facet_node<const T, OFF32>(prm.scale, fl.code(a))
+                     : T(0);
+    }
     T tq[P];
     stokes_pressure_at_nodes<T, P, PP>(prm, e, w, s0, tq);
     if (has_succ) fn.finish(traw, w.i, w.j);
@@ -229,7 +239,10 @@ stokes_grad_t_chain_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
           acc[a] += s0[w.own_w + a * L::A] + s1[w.own_w + a * L::A];
         // a diagonal factor that is the same on every copy of a node
         // commutes with the assembly (E = D QQ^T (Q . D^T))
-        if (has_scale) {
+        if (scale_node) {
+#pragma unroll
+          for (int a = 0; a < P; ++a) acc[a] *= sc[a];
+        } else if (has_scale) {
           const T* sg = prm.scale + c * prm.scale_comp_stride;
 #pragma unroll
           for (int a = 0; a < P; ++a) {
@@ -313,6 +326,8 @@ stokes_div_chain_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
         asm volatile("" : "+v"(cd[a]));
         ua[a] = w.ok ? *facet_node<const T, OFF32>(ug, cd[a]) : T(0);
       }
+      // (a per-node factor is re-read per component: holding it across the
+      // three costs 16 registers and measured 1.54 vs 1.21 ms without scale)
       if (has_scale) {
         const T* sg = prm.scale + c * prm.scale_comp_stride;
 #pragma unroll
