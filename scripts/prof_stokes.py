@@ -27,10 +27,15 @@ scale = torch.rand(N, dtype=torch.float64, device=dev) + 0.5
 p = torch.randn(psp.mesh.num_nodes, dtype=torch.float64, device=dev)
 pout, out = torch.empty_like(p), torch.empty_like(u)
 so = 0 if op.shared_order is None else 2 * op.shared_order.shape[1]
-# bytes a launch has to move (affine / multilinear geometry: 24 reals per element)
+# bytes a launch has to move (affine / multilinear geometry: 24 reals per
+# element); connectivity: 432 B of facet table + 4 B of chain list per element,
+# or the index row (+ the sorted slot list for the scatter)
+facet = op.facet_parts is not None and all('facet_table' in q for q in op.facet_parts)
+conn_div = 436 * E if facet else 4 * E * nn
+conn_grad = 436 * E if facet else (4 * nn + so) * E
 must = {
-    'stokes_div': 4 * E * nn + 3 * s * N + s * N + 24 * s * E + s * E * npp,
-    'stokes_grad_t': 4 * E * nn + so * E + s * E * npp + 24 * s * E + 3 * s * N,
+    'stokes_div': conn_div + 3 * s * N + s * N + 24 * s * E + s * E * npp,
+    'stokes_grad_t': conn_grad + s * E * npp + 24 * s * E + 3 * s * N,
 }
 def timeit(fn):
   for _ in range(3): fn()
@@ -40,7 +45,7 @@ def timeit(fn):
     a.record(); fn(); b.record()
   torch.cuda.synchronize()
   return sum(a.elapsed_time(b) for a, b in ev) / reps
-res = {'n': n, 'P': P, 'velocity_dofs': 3 * N, 'pressure_dofs': E * npp,
+res = {'n': n, 'P': P, 'connectivity': 'facet table + chains' if facet else 'index rows', 'velocity_dofs': 3 * N, 'pressure_dofs': E * npp,
        'stokes_div': {'ms': timeit(lambda: op.div(u, scale=scale, out=pout)), 'bytes_must_move': must['stokes_div']},
        'stokes_grad_t': {'ms': timeit(lambda: op.grad_t(p, out=out)), 'bytes_must_move': must['stokes_grad_t']}}
 for k in ('stokes_div', 'stokes_grad_t'):
