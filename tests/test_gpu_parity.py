@@ -1215,10 +1215,10 @@ def test_config2_properties_full_size(n):
   assert all(b < a for a, b in zip(errs, errs[1:])), errs
 
 
-@pytest.mark.parametrize('n', [int(os.environ.get('SFEM_TEST_P11_N', '32'))])
+@pytest.mark.parametrize('n', [int(os.environ.get('SFEM_TEST_P11_N', '64'))])
 def test_config5_properties_at_scale(n):
-  """p = 11 fp32 Helmholtz on an n^3 block (config 5's per-GPU block is 64^3:
-  SFEM_TEST_P11_N=64): symmetry, constants in the nullspace of the stiffness
+  """p = 11 fp32 Helmholtz on an n^3 block, by default config 5's full per-GPU
+  block of 64^3 elements (350 M DOFs, 20 s on one MI355X): symmetry, constants in the nullspace of the stiffness
   part, on-the-fly geometry == stored factors, fused p.Ap, within the fp32
   tolerance of the north star (1e-5 relative, scaled by the operator norm)."""
   from swirl_fem_amd import _lib
