@@ -4,7 +4,9 @@
  * Checks, on one affine hex element of P^3 GLL nodes scaled to [0,h]^3:
  *   gather / scatter-add round trip with a -1 sentinel,
  *   stiffness of a constant = 0, mass of a constant sums to the volume,
- *   sfem_dot, error reporting through sfem_last_error().
+ *   sfem_dot, error reporting through sfem_last_error(); the fused apply also
+ *   through the compact connectivity (sfem_facet_table_build,
+ *   sfem_helmholtz_setup_affine, facet table + chains, box and affine).
  * Exit code 0 = all good; prints the failing check otherwise. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -192,6 +194,109 @@ int main(void) {
     double energy = 0.0;
     for (int k = 0; k < N; ++k) energy += lin[k] * out[k];
     CHECK(fabs(energy - h * h * h) < 1e-14, "x^T A x = %.17g", energy);
+  }
+  /* --- the same through compact connectivity: facet table, box constants,
+   *     a chain of one element; P = 6 GLL nodes ---------------------------- */
+  {
+    enum { P = 6, N = P * P * P };
+    const double h = 0.25;
+    const double x1[P] = {-1.0, -0.76505532392946469, -0.28523151648064510,
+                          0.28523151648064510, 0.76505532392946469, 1.0};
+    const double w1[P] = {1.0 / 15, 0.37847495629784698, 0.55485837703548635,
+                          0.55485837703548635, 0.37847495629784698, 1.0 / 15};
+    double bw[P], D[P * P];
+    for (int i = 0; i < P; ++i) {
+      bw[i] = 1.0;
+      for (int j = 0; j < P; ++j)
+        if (j != i) bw[i] /= (x1[i] - x1[j]);
+    }
+    for (int i = 0; i < P; ++i) {
+      double row = 0.0;
+      for (int j = 0; j < P; ++j)
+        if (j != i) {
+          D[i * P + j] = (bw[j] / bw[i]) / (x1[i] - x1[j]);
+          row += D[i * P + j];
+        }
+      D[i * P + i] = -row;
+    }
+    static double coords[N * 3], ones[N], lin[N], out[N];
+    static int32_t elems[N], mult[N];
+    for (int a = 0; a < P; ++a)
+      for (int b = 0; b < P; ++b)
+        for (int c = 0; c < P; ++c) {
+          const int k = (a * P + b) * P + c;
+          coords[3 * k + 0] = h * (x1[a] + 1) / 2;
+          coords[3 * k + 1] = 2 * h * (x1[b] + 1) / 2;      /* a box, not a cube */
+          coords[3 * k + 2] = 3 * h * (x1[c] + 1) / 2;
+          ones[k] = 1.0;
+          lin[k] = coords[3 * k + 1];                       /* u = y         */
+          elems[k] = k;
+          mult[k] = 1;
+        }
+    const double vol = 6 * h * h * h;
+    double* dco = (double*)to_device(coords, sizeof coords);
+    double* dge = (double*)to_device(NULL, 24 * sizeof(double));
+    double* dcs = (double*)to_device(NULL, 8 * sizeof(double));
+    int32_t* del = (int32_t*)to_device(elems, sizeof elems);
+    int32_t* dmu = (int32_t*)to_device(mult, sizeof mult);
+    int32_t* dtab = (int32_t*)to_device(NULL, 27 * 4 * sizeof(int32_t));
+    uint8_t* dok = (uint8_t*)to_device(NULL, 1);
+    const int32_t offsets[2] = {0, 1}, chain[1] = {0};
+    int32_t* doff = (int32_t*)to_device(offsets, sizeof offsets);
+    int32_t* dch = (int32_t*)to_device(chain, sizeof chain);
+    double* du1 = (double*)to_device(ones, sizeof ones);
+    double* dux = (double*)to_device(lin, sizeof lin);
+    double* dout = (double*)to_device(NULL, sizeof out);
+    CHECK(dco && dge && dcs && del && dmu && dtab && dok && doff && dch && du1 &&
+              dux && dout, "hipMalloc");
+    CHECK(sfem_facet_table_build(del, NULL, dmu, dtab, dok, 1, N, P, NULL) ==
+              SFEM_OK, "%s", sfem_last_error());
+    uint8_t ok = 0;
+    int32_t tab[27 * 4];
+    HIP(hipMemcpy(&ok, dok, 1, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(tab, dtab, sizeof tab, hipMemcpyDeviceToHost));
+    CHECK(ok == 1, "lexicographic ids are 27 affine facet maps");
+    /* facet 13 = the element interior: first node (1,1,1), strides P^2, P, 1 */
+    CHECK(tab[13 * 4] == (P + 1) * P + 1 && tab[13 * 4 + 1] == P * P &&
+              tab[13 * 4 + 2] == P && tab[13 * 4 + 3] == 1, "interior facet");
+    CHECK(sfem_helmholtz_setup_multilinear(dco, dge, 1, 3, P, SFEM_F64, NULL) ==
+              SFEM_OK, "%s", sfem_last_error());
+    CHECK(sfem_helmholtz_setup_affine(dge, dcs, 1, 1e-13, SFEM_F64, NULL) ==
+              SFEM_OK, "%s", sfem_last_error());
+    double cst[8];
+    HIP(hipMemcpy(cst, dcs, sizeof cst, hipMemcpyDeviceToHost));
+    CHECK(cst[7] == 1.0 && fabs(cst[6] - vol / 8) < 1e-15, "box, detJ = %g",
+          cst[6]);
+    sfem_helmholtz_args a;
+    memset(&a, 0, sizeof a);
+    a.out = dout; a.geo_elem = dge; a.geo_const = dcs; a.facet_table = dtab;
+    a.chain_offsets = doff; a.chain_elems = dch; a.num_chains = 1;
+    a.dmat = D; a.weights = w1; a.nodes = x1;
+    a.num_elements = 1; a.num_nodes = N; a.ndim = 3; a.P = P; a.ncomp = 1;
+    a.dtype = SFEM_F64;
+    for (int mode = 0; mode < 2; ++mode) {      /* box, then general affine */
+      a.geo_mode = mode == 0 ? SFEM_GEO_BOX : SFEM_GEO_AFFINE;
+      a.u = du1; a.lambda0 = 0.0; a.lambda1 = 1.0;
+      CHECK(sfem_helmholtz_apply(&a, NULL) == SFEM_OK, "%s", sfem_last_error());
+      HIP(hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost));
+      for (int k = 0; k < N; ++k)
+        CHECK(fabs(out[k]) < 1e-13, "facet A 1 [%d] = %g", k, out[k]);
+      a.lambda0 = 1.0; a.lambda1 = 0.0;
+      CHECK(sfem_helmholtz_apply(&a, NULL) == SFEM_OK, "%s", sfem_last_error());
+      HIP(hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost));
+      double sum = 0.0;
+      for (int k = 0; k < N; ++k) sum += out[k];
+      CHECK(fabs(sum - vol) < 1e-13, "facet sum B 1 = %.17g", sum);
+      a.u = dux; a.lambda0 = 0.0; a.lambda1 = 1.0;   /* y^T A y = volume */
+      CHECK(sfem_helmholtz_apply(&a, NULL) == SFEM_OK, "%s", sfem_last_error());
+      HIP(hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost));
+      double energy = 0.0;
+      for (int k = 0; k < N; ++k) energy += lin[k] * out[k];
+      CHECK(fabs(energy - vol) < 1e-13, "facet y^T A y = %.17g", energy);
+    }
+    /* SFEM_GEO_BOX without a facet table is refused */
+    a.facet_table = NULL; a.geo_mode = SFEM_GEO_BOX;
+    CHECK(sfem_helmholtz_apply(&a, NULL) != SFEM_OK, "box without table");
   }
   HIP(hipDeviceSynchronize());
   printf("c-abi OK\n");
