@@ -194,3 +194,62 @@ def test_linear_operators_stay_on_the_fused_kernels_under_autograd(monkeypatch):
       lhs = float((op(v) * w).sum())
     rhs = float((g * v).sum())
     assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), 1.0), name
+
+
+def test_vmap_over_an_ensemble_matches_item_by_item():
+  """The reference vmaps gather / scatter and the solver step over an ensemble
+  (niles/train.py:232, :262-264); `core.batching.vmap` gives the same call
+  shape: stacked results equal the item-by-item calls, gradients flow to a
+  batched forcing through every item's solves."""
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.core.batching import vmap
+  from swirl_fem_amd.examples.navier_stokes_driver import navier_stokes_step
+  from swirl_fem_amd.navier_stokes.navier_stokes import StokesSEM
+  sem = StokesSEM.create(unit_cube_mesh(3, ndim=2, periodic_dims=(0, 1)), {},
+                         order=4, device=DEV)
+  mesh = sem.velocity.mesh
+  g = torch.Generator(device=DEV).manual_seed(3)
+  B = 3
+  u0 = 0.1 * torch.randn(B, mesh.num_nodes, 2, dtype=torch.float64, device=DEV,
+                         generator=g)
+  u0 = vmap(sem.velocity.exchange)(u0) / vmap(sem.velocity.exchange)(
+      torch.ones_like(u0))
+  # gather / scatter over the ensemble
+  loc = vmap(sem.velocity.gather)(u0)
+  assert loc.shape == (B, mesh.num_elements, mesh.num_nodes_per_element, 2)
+  assert torch.equal(loc[1], sem.velocity.gather(u0[1]))
+  back = vmap(sem.velocity.scatter)(loc)
+  assert torch.equal(back[2], sem.velocity.scatter(loc[2]))
+  p0 = torch.zeros(B, sem.pressure.pspace.mesh.num_nodes, dtype=torch.float64,
+                   device=DEV)
+  forcing = (0.05 * torch.randn(B, mesh.num_nodes, 2, dtype=torch.float64,
+                                device=DEV, generator=g)).requires_grad_(True)
+
+  def one(u, p, f):
+    us, ps = (u, u), (p, p)
+    cu = sem.C(u)
+    un, pn, cn, aux = navier_stokes_step(
+        sem, us, ps, (cu, cu), reynolds=50.0, dt=1e-2, time_order=2,
+        forcing=f, tol=1e-12, atol=0.0)
+    return un, pn, aux['u_star_info']['num_iterations']
+
+  un, pn, iters = vmap(one)(u0, p0, forcing)
+  assert un.shape == u0.shape and pn.shape == p0.shape and len(iters) == B
+  for b in range(B):
+    ub, pb, _ = one(u0[b], p0[b], forcing[b].detach())
+    assert float((un[b] - ub).abs().max()) <= 1e-12 * float(ub.abs().max())
+    assert float((pn[b] - pb).abs().max()) <= 1e-10 * max(
+        1.0, float(pb.abs().max()))
+  # d/d forcing of a functional of the ensemble: item b only sees forcing[b]
+  w = torch.randn(un.shape, dtype=un.dtype, device=DEV, generator=g)
+  (un * w).sum().backward()
+  gb = forcing.grad
+  f2 = forcing.detach()[1].clone().requires_grad_(True)
+  u1, _, _ = one(u0[1], p0[1], f2)
+  (u1 * w[1]).sum().backward()
+  assert float((gb[1] - f2.grad).abs().max()) <= 1e-10 * float(
+      f2.grad.abs().max())
+  # in_axes = None keeps an argument whole
+  same = vmap(lambda u, s: s * u, in_axes=(0, None))(u0, torch.tensor(
+      2.0, dtype=torch.float64, device=DEV))
+  assert torch.equal(same, 2.0 * u0)
