@@ -43,7 +43,7 @@ def algorithmic_bytes_per_apply(E, n, N, sizeof=8, ngeo=6):
 # --elems^3), measured on one MI355X and committed under profiles/: the first
 # real scaling record can then be read as the speed-up north_star asks for.
 STRONG_REF = {   # (global elements per direction, p, dtype) -> (ms, source)
-    (128, 7, 'f64'): (15.7, 'profiles/r01_bench_n128_single_gpu.json'),
+    (128, 7, 'f64'): (12.4, 'profiles/r03_bench_n128_single_gpu.json'),
 }
 
 
