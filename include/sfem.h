@@ -196,7 +196,9 @@ int sfem_basis_eval_t(const void* c0, const void* c1, const void* interp1,
  * elements, so a mesh mixing the kinds is applied by one call per kind.       */
 enum { SFEM_GEO_POINT = 0, SFEM_GEO_AFFINE = 1, SFEM_GEO_MULTILINEAR = 3,
        SFEM_GEO_BOX = 5 /* affine with diagonal J^-1 J^-T (Cartesian boxes):  */
-                        /* facet-table applies only, needs `geo_const`        */ };
+                        /* facet-table applies only.  Helmholtz: needs        */
+                        /* `geo_const`; Stokes: `geo_elem` whose Jacobian is  */
+                        /* itself diagonal (x_c depends on reference axis c)  */ };
 
 int sfem_helmholtz_setup(const void* invjac, const void* jacdet,
                          const void* weights_nd /* (Q,) */, void* geo,
@@ -287,8 +289,9 @@ typedef struct sfem_helmholtz_args {
   const int32_t* facet_table;
   const void* geo_const;  /* (E, 8) from sfem_helmholtz_setup_affine: needed  */
                           /*   with facet_table for SFEM_GEO_AFFINE / _BOX    */
-  /* facet_table applies of SCALAR fields: the elements as chains (NULL / 0 = */
-  /* one workgroup per listed element).  Segment s is the elements            */
+  /* facet_table applies of scalar or component-major (node_stride = 1)       */
+  /* fields, the latter one launch per component: the elements as chains      */
+  /* (NULL / 0 = one workgroup per listed element).  Segment s is the elements */
   /* chain_elems[chain_offsets[s] .. chain_offsets[s+1]); inside a segment    */
   /* the face a = P-1 of every element IS the face a = 0 of the next, node    */
   /* for node: elements[e][(P-1) P^2 + t] == elements[next][t], t < P^2.      */
@@ -398,6 +401,9 @@ typedef struct sfem_stokes_args {
   /* sfem_helmholtz_args (NULL = off; `enc` / `shared_order` are then not     */
   /* read).  Both are needed: a launch without chains passes segments of one  */
   /* element.  The segments must hold every element of the launch once.       */
+  /* geo_mode SFEM_GEO_BOX (these launches only): elements whose `geo_elem`   */
+  /* has a diagonal constant Jacobian -- component c of div / grad_t then     */
+  /* takes the one 1D derivative along axis c.                                */
   const int32_t* facet_table;     /* (E, 27, 4) from sfem_facet_table_build   */
   const int32_t* chain_offsets;   /* (num_chains + 1,)                        */
   const int32_t* chain_elems;

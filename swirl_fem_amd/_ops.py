@@ -442,7 +442,11 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
   ch = None
   if ft is not None:
     so = None
-    if not vec and os.environ.get('SFEM_CHAIN', '1') != '0':
+    # chains walk scalar fields; a component-major vector field is walked
+    # component by component
+    if ((not vec or node_stride == 1) and
+        os.environ.get('SFEM_CHAIN', '1') != '0' and
+        (not vec or os.environ.get('SFEM_CHAIN_VECTOR', '1') != '0')):
       ch = part.get('chains')        # (offsets, elems) int32 device tensors
   return _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),

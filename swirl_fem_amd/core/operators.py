@@ -708,14 +708,21 @@ class StokesDivGrad:
     if os.environ.get('SFEM_CHAIN', '1') == '0':
       seg_len = 1
     every = torch.arange(E, device=ok.device)
+    use_box = os.environ.get('SFEM_BOX', '1') != '0'
     out = []
     for part in parts:
       ids = every if 'elem_list' not in part else part['elem_list'].long()
       good = ok[ids]
-      for sel, facet in ((ids[good], True), (ids[~good], False)):
+      box = torch.zeros_like(good)
+      if part['geo_mode'] == _GEO_AFFINE and use_box:
+        box = good & _diagonal_jacobian(part['geo_elem'][ids])
+      for sel, facet, mode in ((ids[box], True, _GEO_BOX),
+                               (ids[good & ~box], True, part['geo_mode']),
+                               (ids[~good], False, part['geo_mode'])):
         if sel.numel() == 0:
           continue
         new = {k: v for k, v in part.items() if k != 'elem_list'}
+        new['geo_mode'] = mode
         if sel.numel() < E:
           new['elem_list'] = sel.to(torch.int32).contiguous()
         if facet:
@@ -842,6 +849,21 @@ class StokesDivGrad:
                               self._parts_for(out), self.host, mesh.ndim,
                               mesh.gridpoints_1d.num_points, self.zero_range,
                               self.shared_order, scale)
+
+
+def _diagonal_jacobian(coef):
+  """(E,) bool: rows of the (E, 24) multilinear coefficients whose map is
+  x_c = x0_c + h_c * xi_c (axis-aligned boxes in the element's own axis order):
+  the Stokes kernels then need one derivative per component
+  (`SFEM_GEO_BOX`)."""
+  lin = coef[:, :9].reshape(-1, 3, 3)            # d x_c / d xi_k at [k, c]
+  diag = torch.diagonal(lin, dim1=1, dim2=2).abs()
+  scale = diag.max(dim=1).values
+  tol = BOX_TOL[coef.dtype] * scale
+  off = lin.abs() * (1 - torch.eye(3, dtype=coef.dtype, device=coef.device))
+  higher = coef[:, 9:21].abs().max(dim=1).values
+  return ((off.reshape(-1, 9).max(dim=1).values <= tol) & (higher <= tol) &
+          (diag.min(dim=1).values > 0))
 
 
 def _like_layout(t, ref):

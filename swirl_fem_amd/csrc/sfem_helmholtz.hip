@@ -277,6 +277,21 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
     fp.dot_out = prm.dot_out;
     fp.chain_off = c.chain_offsets;
     fp.chain_elems = c.chain_elems;
+    if (c.chain_offsets && c.ncomp > 1) {
+      // component-major vector field: every component is a scalar field of
+      // its own strip, walked by the (scalar) chain kernel
+      for (int k = 0; k < c.ncomp; ++k) {
+        FacetParams<T> fk = fp;
+        fk.u = prm.u + (int64_t)k * prm.comp_stride;
+        fk.out = prm.out + (int64_t)k * prm.comp_stride;
+        fk.ncomp = 1;
+        const int rc = dispatch_helmholtz_facet<T>(
+            fk, c.P, c.geo_mode, c.num_chains, c.num_nodes, prm.dmat_host,
+            prm.weights_host, prm.nodes_host, stream);
+        if (rc != SFEM_OK) return rc;
+      }
+      return SFEM_OK;
+    }
     return dispatch_helmholtz_facet<T>(fp, c.P, c.geo_mode,
                                        c.chain_offsets ? c.num_chains
                                                        : c.num_elements,
@@ -447,9 +462,10 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
     c.geo_const = a->geo_const;
     c.num_nodes = a->num_nodes;
     if (a->chain_offsets) {
-      SFEM_REQUIRE(a->chain_elems && a->num_chains > 0 && a->ncomp == 1,
+      SFEM_REQUIRE(a->chain_elems && a->num_chains > 0 &&
+                       (a->ncomp == 1 || a->node_stride == 1),
                    "sfem_helmholtz_apply: chains need chain_elems, "
-                   "num_chains > 0 and a scalar field");
+                   "num_chains > 0 and a scalar or component-major field");
       c.chain_offsets = a->chain_offsets;
       c.chain_elems = a->chain_elems;
       c.num_chains = a->num_chains;

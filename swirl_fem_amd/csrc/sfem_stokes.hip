@@ -78,10 +78,13 @@ static int check_stokes(const char* who, const sfem_stokes_args* a) {
   if (a->geo_mode == SFEM_GEO_POINT) {
     SFEM_REQUIRE(a->kfac, "%s: per-point geometry needs `kfac`", who);
   } else if (a->geo_mode == SFEM_GEO_AFFINE ||
-             a->geo_mode == SFEM_GEO_MULTILINEAR) {
+             a->geo_mode == SFEM_GEO_MULTILINEAR ||
+             a->geo_mode == SFEM_GEO_BOX) {
     SFEM_REQUIRE(a->geo_elem && a->weights && a->nodes,
                  "%s: on-the-fly geometry needs geo_elem, weights and nodes",
                  who);
+    SFEM_REQUIRE(a->geo_mode != SFEM_GEO_BOX || a->facet_table,
+                 "%s: SFEM_GEO_BOX is a facet-table (chain) launch", who);
   } else {
     set_error("%s: unknown geo_mode %d", who, a->geo_mode);
     return SFEM_EINVAL;

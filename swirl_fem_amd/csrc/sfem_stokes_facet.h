@@ -428,6 +428,309 @@ stokes_div_chain_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Axis-aligned box elements (geo_mode SFEM_GEO_BOX): x_c depends on the
+// reference coordinate of axis c only, so the weighted cofactor matrix is the
+// constant diagonal  K_cc = w_q h_(c+1) h_(c+2)  (h_c = A[4 c], the half edge
+// of geo_elem) and component c of D^T p / D u takes ONE 1D derivative -- along
+// axis c -- instead of three: axis 0 in registers, axes 1 and 2 one LDS pass
+// each.  Same chain walk, tables and scatter as the kernels above.
+#ifndef SFEM_STOKES_BOX_MINW
+#define SFEM_STOKES_BOX_MINW 4
+#endif
+#ifndef SFEM_STOKES_BOX_GRAD_MINW
+#define SFEM_STOKES_BOX_GRAD_MINW 3
+#endif
+
+template <typename T>
+__device__ __forceinline__ void stokes_box_cof(const StokesParams<T>& prm,
+                                               int64_t e, T (&kd)[3]) {
+  const T* A = prm.geo_elem + e * 24;
+  const T hx = A[0], hy = A[4], hz = A[8];
+  kd[0] = hy * hz;
+  kd[1] = hz * hx;
+  kd[2] = hx * hy;
+}
+
+template <typename T, int P, bool OFF32>
+__global__ void __launch_bounds__(64, SFEM_STOKES_BOX_GRAD_MINW)
+stokes_grad_t_box_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
+                         IMat<T, P, P - 2> im) {
+  using L = FacetLayout<P>;
+  constexpr int PP = P - 2;
+  const StokesParams<T>& prm = fprm.base;
+  __shared__ T lds[2 * L::COPY];
+  T* s0 = lds;
+  uint32_t* codes = reinterpret_cast<uint32_t*>(lds + L::COPY);
+
+  FacetWave<P> w;
+  w.init();
+  const int32_t k0 = fprm.chain_off[blockIdx.x];
+  const int32_t k1 = fprm.chain_off[blockIdx.x + 1];
+  uint16_t slots[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) slots[q] = g_facet_slots<P>.s[w.lane][q];
+  const bool face_inner = FacetLane<P>::cls(w.i) == 1 &&
+                          FacetLane<P>::cls(w.j) == 1;
+  const int64_t ks = prm.comp_stride;
+  const DMat<T, P>* kdm = reinterpret_cast<const DMat<T, P>*>(
+      kernarg_bytes() + StokesKernarg<T, P>::DM_OFF);
+  const T lane_w = kdm->w[w.i] * kdm->w[w.j];
+  const bool has_scale = prm.scale != nullptr;
+  const bool scale_node = has_scale && prm.scale_comp_stride == 0;
+
+  FacetLane<P> fl, fn;
+  typename FacetLane<P>::Raw traw;
+  fl.load(fprm.tab, (int64_t)fprm.chain_elems[k0], w.i, w.j);
+  fn = fl;
+  if (k0 + 1 < k1)
+    FacetLane<P>::issue(traw, fprm.tab, (int64_t)fprm.chain_elems[k0 + 1],
+                        w.i, w.j);
+  T carry[3] = {T(0), T(0), T(0)};
+  for (int32_t k = k0; k < k1; ++k) {
+    const bool has_pred = k > k0, has_succ = k + 1 < k1;
+    const int64_t e = (int64_t)fprm.chain_elems[k];
+    T kd[3];
+    stokes_box_cof<T>(prm, e, kd);
+    T sc[P];
+    if (scale_node) {
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+        sc[a] = w.ok ? *facet_node<const T, OFF32>(prm.scale, fl.code(a))
+                     : T(0);
+    }
+    T tq[P];
+    stokes_pressure_at_nodes<T, P, PP>(prm, e, w, s0, tq);
+    if (has_succ) fn.finish(traw, w.i, w.j);
+    if (k + 2 < k1)
+      FacetLane<P>::issue(traw, fprm.tab, (int64_t)fprm.chain_elems[k + 2],
+                          w.i, w.j);
+    FacetLane<P> fe = fl;
+    if (has_pred && face_inner) fe.t[0] &= ~(uint32_t)SFEM_IDX_SHARED;
+    if (has_succ) fe.t[2] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
+#if defined(SFEM_STOKES_TIMING)   // timing only: traffic of 2 x 2 bundles
+    {
+      const int pi = ((int)e >> 6) & 1, pj = (int)e & 1;
+      const bool don = (pi == 0 && w.i == P - 1) || (pj == 0 && w.j == P - 1);
+      const bool out_i = pi == 0 ? w.i == 0 : w.i == P - 1;
+      const bool out_j = pj == 0 ? w.j == 0 : w.j == P - 1;
+      const bool com = ((pi == 1 && w.i == 0) && !out_j) ||
+                       ((pj == 1 && w.j == 0) && !out_i);
+      if (don || (com && SFEM_STOKES_TIMING == 10)) {
+        if (don || has_pred) fe.t[0] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
+        fe.t[1] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
+        if (don) fe.t[2] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
+      }
+    }
+#endif
+    {   // quadrature weight of the node
+      const SFEM_CONSTANT_AS DMat<T, P>* km = StokesKernarg<T, P>::dm();
+#pragma unroll
+      for (int a = 0; a < P; ++a) tq[a] *= lane_w * km->w[a];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      T acc[P];
+      if (c == 0) {
+        T x[P];
+#pragma unroll
+        for (int a = 0; a < P; ++a) x[a] = kd[0] * tq[a];
+        line_apply_mem<T, P, true>(StokesKernarg<T, P>::dm(), x, acc);
+      } else {
+        if (w.ok) {
+#pragma unroll
+          for (int a = 0; a < P; ++a) s0[w.own_w + a * L::A] = kd[c] * tq[a];
+        }
+        facet_sync<P>();
+        if (w.ok) {
+          T x[P], y[P];
+#pragma unroll
+          for (int m = 0; m < P; ++m)
+            x[m] = c == 1 ? s0[w.mid_w + m * L::B] : s0[w.last_w + m];
+          line_apply_mem<T, P, true>(StokesKernarg<T, P>::dm(), x, y);
+#pragma unroll
+          for (int m = 0; m < P; ++m) {
+            if (c == 1) s0[w.mid_w + m * L::B] = y[m];
+            else s0[w.last_w + m] = y[m];
+          }
+        }
+        facet_sync<P>();
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+          acc[a] = w.ok ? s0[w.own_w + a * L::A] : T(0);
+        facet_sync<P>();
+      }
+      T* og = prm.out + c * ks;
+      if (w.ok) {
+        if (scale_node) {
+#pragma unroll
+          for (int a = 0; a < P; ++a) acc[a] *= sc[a];
+        } else if (has_scale) {
+          const T* sg = prm.scale + c * prm.scale_comp_stride;
+#pragma unroll
+          for (int a = 0; a < P; ++a) {
+            uint32_t code = fl.code(a);
+            asm volatile("" : "+v"(code));
+            acc[a] *= *facet_node<const T, OFF32>(sg, code);
+          }
+        }
+      }
+      if (has_pred) acc[0] += carry[c];
+      carry[c] = acc[P - 1];
+      if (w.ok) {
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+          if (fe.flags(a) & SFEM_IDX_DIRICHLET) acc[a] = T(0);
+      }
+      facet_scatter_tail<T, P, OFF32>(fe, slots, acc, og, s0, codes, w.own_w,
+                                      w.ok);
+      facet_sync<P>();
+    }
+    fl = fn;
+  }
+}
+
+template <typename T, int P, bool OFF32>
+__global__ void __launch_bounds__(64, SFEM_STOKES_BOX_MINW)
+stokes_div_box_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
+                      IMat<T, P, P - 2> im) {
+  using L = FacetLayout<P>;
+  constexpr int PP = P - 2, NP = PP * PP * PP;
+  const StokesParams<T>& prm = fprm.base;
+  __shared__ T lds[L::COPY];
+  T* s0 = lds;
+
+  FacetWave<P> w;
+  w.init();
+  const int i = w.i, j = w.j;
+  const int32_t k0 = fprm.chain_off[blockIdx.x];
+  const int32_t k1 = fprm.chain_off[blockIdx.x + 1];
+  const int64_t ks = prm.comp_stride;
+  const DMat<T, P>* kdm = reinterpret_cast<const DMat<T, P>*>(
+      kernarg_bytes() + StokesKernarg<T, P>::DM_OFF);
+  const T lane_w = kdm->w[w.i] * kdm->w[w.j];
+  const bool has_scale = prm.scale != nullptr;
+
+  FacetLane<P> fl, fn;
+  typename FacetLane<P>::Raw traw;
+  fl.load(fprm.tab, (int64_t)fprm.chain_elems[k0], w.i, w.j);
+  fn = fl;
+  if (k0 + 1 < k1)
+    FacetLane<P>::issue(traw, fprm.tab, (int64_t)fprm.chain_elems[k0 + 1],
+                        w.i, w.j);
+  T u_last[3] = {T(0), T(0), T(0)};   // scaled values of the carried face
+  double pdot = 0.0;
+  for (int32_t k = k0; k < k1; ++k) {
+    const bool has_pred = k > k0, has_succ = k + 1 < k1;
+    const int64_t e = (int64_t)fprm.chain_elems[k];
+    T kd[3];
+    stokes_box_cof<T>(prm, e, kd);
+    T tq[P];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      T ua[P];
+      const T* ug = prm.u + c * ks;
+      uint32_t cd[P];
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        cd[a] = fl.code(a);
+        asm volatile("" : "+v"(cd[a]));
+        ua[a] = w.ok ? *facet_node<const T, OFF32>(ug, cd[a]) : T(0);
+      }
+      if (has_scale) {
+        const T* sg = prm.scale + c * prm.scale_comp_stride;
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+          if (w.ok) ua[a] *= *facet_node<const T, OFF32>(sg, cd[a]);
+      }
+      if (has_pred) ua[0] = u_last[c];
+      u_last[c] = ua[P - 1];
+      if (c == 0) {   // the next table travels with this element's first gather
+        if (has_succ) fn.finish(traw, w.i, w.j);
+        if (k + 2 < k1)
+          FacetLane<P>::issue(traw, fprm.tab,
+                              (int64_t)fprm.chain_elems[k + 2], w.i, w.j);
+        T d0[P];
+        line_apply_mem<T, P, false>(StokesKernarg<T, P>::dm(), ua, d0);
+#pragma unroll
+        for (int a = 0; a < P; ++a) tq[a] = kd[0] * d0[a];
+      } else {
+        if (w.ok) {
+#pragma unroll
+          for (int a = 0; a < P; ++a) s0[w.own_w + a * L::A] = ua[a];
+        }
+        facet_sync<P>();
+        if (w.ok) {
+          T x[P], y[P];
+#pragma unroll
+          for (int m = 0; m < P; ++m)
+            x[m] = c == 1 ? s0[w.mid_w + m * L::B] : s0[w.last_w + m];
+          line_apply_mem<T, P, false>(StokesKernarg<T, P>::dm(), x, y);
+#pragma unroll
+          for (int m = 0; m < P; ++m) {
+            if (c == 1) s0[w.mid_w + m * L::B] = y[m];
+            else s0[w.last_w + m] = y[m];
+          }
+        }
+        facet_sync<P>();
+        if (w.ok) {
+#pragma unroll
+          for (int a = 0; a < P; ++a) tq[a] += kd[c] * s0[w.own_w + a * L::A];
+        }
+        facet_sync<P>();
+      }
+    }
+    {
+      const SFEM_CONSTANT_AS DMat<T, P>* km = StokesKernarg<T, P>::dm();
+#pragma unroll
+      for (int a = 0; a < P; ++a) tq[a] *= lane_w * km->w[a];
+    }
+    // projection onto the pressure basis: axis 0 in registers, then LDS lines
+    {
+      T r[PP];
+      interp_t_mem<T, P, PP>(StokesKernarg<T, P>::im(), tq, r);
+      if (w.ok) {
+#pragma unroll
+        for (int q = 0; q < PP; ++q) s0[L::word(q, i, j)] = r[q];
+      }
+    }
+    facet_sync<P>();
+    if (w.ok && i < PP) {   // line [k0 = i, *, j]
+      T x[P], y[PP];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = s0[L::word(i, m, j)];
+      interp_t_mem<T, P, PP>(StokesKernarg<T, P>::im(), x, y);
+#pragma unroll
+      for (int q = 0; q < PP; ++q) s0[L::word(i, q, j)] = y[q];
+    }
+    facet_sync<P>();
+    if (w.ok && i < PP && j < PP) {   // line [k0 = i, k1 = j, *]
+      T x[P], y[PP];
+#pragma unroll
+      for (int m = 0; m < P; ++m) x[m] = s0[L::word(i, j, m)];
+      interp_t_mem<T, P, PP>(StokesKernarg<T, P>::im(), x, y);
+      const int32_t* penc0 = prm.penc ? prm.penc + e * NP : nullptr;
+#pragma unroll
+      for (int q = 0; q < PP; ++q) {
+        const int slot = (i * PP + j) * PP + q;
+        const int64_t pid = penc0 ? (int64_t)penc0[slot] : e * NP + slot;
+        if (pid >= 0) {
+          prm.p_out[pid] = y[q];
+          if (prm.dot_out) pdot += (double)y[q] * (double)prm.p_in[pid];
+        }
+      }
+    }
+    facet_sync<P>();
+    fl = fn;
+  }
+  if (prm.dot_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pdot += __shfl_down(pdot, off, 64);
+    if (w.lane == 0)
+      unsafeAtomicAdd(&prm.dot_out[blockIdx.x & (SFEM_DOT_SLOTS - 1)], pdot);
+  }
+}
+
 // mode 0 = div, 1 = grad_t
 template <typename T, int P>
 int launch_stokes_facet(const StokesFacetParams<T>& fprm, int mode,
@@ -468,6 +771,23 @@ int launch_stokes_facet(const StokesFacetParams<T>& fprm, int mode,
     }                                                                         \
   } while (0)
   switch (prm.geo_mode) {
+    case GEO_BOX:
+      if (mode == 1) {
+        if (off32)
+          hipLaunchKernelGGL((stokes_grad_t_box_kernel<T, P, true>), grid,
+                             block, 0, stream, fprm, dm, im);
+        else
+          hipLaunchKernelGGL((stokes_grad_t_box_kernel<T, P, false>), grid,
+                             block, 0, stream, fprm, dm, im);
+      } else {
+        if (off32)
+          hipLaunchKernelGGL((stokes_div_box_kernel<T, P, true>), grid, block,
+                             0, stream, fprm, dm, im);
+        else
+          hipLaunchKernelGGL((stokes_div_box_kernel<T, P, false>), grid, block,
+                             0, stream, fprm, dm, im);
+      }
+      break;
     case GEO_POINT: SFEM_STOKES_FACET_GO(GEO_POINT); break;
     case GEO_AFFINE: SFEM_STOKES_FACET_GO(GEO_AFFINE); break;
     default: SFEM_STOKES_FACET_GO(GEO_MULTILINEAR); break;

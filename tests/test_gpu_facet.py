@@ -16,6 +16,7 @@ from swirl_fem_amd import _lib, _ops
 from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
 from swirl_fem_amd.core.fespace import FiniteElementSpace
 from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
+from swirl_fem_amd.core import operators
 from swirl_fem_amd.core.mesh_refiner import refine_premesh
 
 pytestmark = pytest.mark.gpu
@@ -287,3 +288,59 @@ def test_chain_segments_follow_the_mesh_size(monkeypatch):
   assert operators.chain_segment_length(64 ** 3) == 8
   monkeypatch.setenv('SFEM_CHAIN_LEN', '5')
   assert operators.chain_segment_length(16 ** 3) == 5
+
+
+@pytest.mark.parametrize('order,periodic', [(7, ()), (7, (0, 1, 2)), (5, (1,)),
+                                            (6, ())])
+def test_stokes_box_kernels_match_index_rows(order, periodic, monkeypatch):
+  """div / grad_t on an anisotropic Cartesian box (SFEM_GEO_BOX chain kernels:
+  one derivative per component) against the index-row kernels and the affine
+  chain kernels, with and without the scale factors of E."""
+  from swirl_fem_amd.common.premesh_commons import box_mesh
+  from swirl_fem_amd.core import layout
+  from swirl_fem_amd.navier_stokes.navier_stokes import StokesSEM
+  pm = box_mesh((5, 4, 3), (0.0, -1.0, 0.5), (2.0, 0.2, 3.5),
+                periodic_dims=periodic)
+  bcs = {} if len(periodic) == 3 else {'boundary': (1, 0.0)}
+  monkeypatch.setenv('SFEM_CHAIN_LEN', '3')
+
+  def build(**env):
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    sem = StokesSEM.create(pm, bcs, order=order, device=DEV)
+    op = sem._divgrad()
+    for k in env:
+      monkeypatch.delenv(k)
+    return sem, op
+
+  sem, op = build()
+  modes = [q['geo_mode'] for q in op.facet_parts]
+  assert modes == [operators._GEO_BOX], modes
+  _, op_aff = build(SFEM_BOX='0')
+  assert [q['geo_mode'] for q in op_aff.facet_parts] == [operators._GEO_AFFINE]
+  _, op_rows = build(SFEM_STOKES_FACET='0')
+  assert op_rows.facet_parts is None
+  nv, npr = sem.velocity.mesh.num_nodes, op.num_pressure_nodes
+  g = torch.Generator(device='cpu').manual_seed(order)
+  p = torch.randn(npr, dtype=torch.float64, generator=g).to(DEV)
+  u = layout.empty_component_major((nv, 3), torch.float64, torch.device(DEV))
+  u.copy_(torch.randn(nv, 3, dtype=torch.float64, generator=g).to(DEV))
+  s1 = (torch.rand(nv, dtype=torch.float64, generator=g) + 0.5).to(DEV)
+  s3 = layout.empty_component_major((nv, 3), torch.float64, torch.device(DEV))
+  s3.copy_((torch.rand(nv, 3, dtype=torch.float64, generator=g) + 0.5).to(DEV))
+  for scale in (None, s1, s3):
+    want = op_rows.grad_t(p, component_major=True, scale=scale)
+    for other in (op, op_aff):
+      got = other.grad_t(p, component_major=True, scale=scale)
+      err = (got - want).abs().max() / want.abs().max()
+      assert err < 1e-13, ('grad_t', scale is not None, float(err))
+    want = op_rows.div(u, scale=scale)
+    for other in (op, op_aff):
+      got = other.div(u, scale=scale)
+      err = (got - want).abs().max() / want.abs().max()
+      assert err < 1e-13, ('div', scale is not None, float(err))
+  # the fused p . (D u) of the pressure CG
+  dots = torch.zeros(1024, dtype=torch.float64, device=DEV)
+  got = op.div(u, dot_with=p, dot_out=dots)
+  assert abs(float(dots.sum()) - float(p @ got)) < 1e-10 * float(
+      p.norm() * got.norm())
