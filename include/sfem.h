@@ -449,6 +449,7 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  *   [0] gamma = r.M r   [1] p.Ap   [2] gamma_new   [3] alpha   [4] beta
  *   [5] b.b   [6] atol2 = max(tol^2 b.b, atol^2)   [7] done (0/1)
  *   [8] iterations   [9] an iteration is open (phases 5 / 6)
+ *   [11] r.Mr - r.r of the iteration, [12] the mean c (sfem_cg_update_xp_mean)
  *   [10] status, SFEM_CG_STATUS_*: why `done` was raised.  Beyond the
  *        reference's stop rule (cg.py:68-73, which reads a negative or NaN
  *        r.Mr as "converged" and divides by any p.Ap) the solve stops with
@@ -490,10 +491,22 @@ int sfem_stokes_e_second(const sfem_stokes_args* args, sfem_stream_t stream);
  * sfem_cg_update_r / sfem_cg_update_xp: the same two updates regrouped into
  *                      8 instead of 9 vector passes (bitwise the same result):
  *                      r -= alpha Ap (+ gamma_new += r.r), then, once beta is
- *                      known,  x += alpha p;  p = z + beta p                   */
+ *                      known,  x += alpha p;  p = z + beta p
+ * sfem_cg_update_r_mean / sfem_cg_update_xp_mean: the same pair for the
+ *                      preconditioner  M r = r - (w . r / total) 1  (the mean
+ *                      projection of the pressure solve, navier_stokes.py:
+ *                      73-78, w = B 1, total = 1 . B 1) without storing z = M r:
+ *                      update_r_mean also sums r.r (striped slots), 1.r and w.r
+ *                      (`sums`: SFEM_CG_MEAN_SUMS device doubles, zero before
+ *                      the first iteration, owned by the solve); update_xp_mean
+ *                      forms c = w.r / total, gamma_new = r.r - c 1.r, beta, and
+ *                      p = (r - c) + beta p.  9 vector passes per iteration
+ *                      instead of 12.  The closing phases of sfem_cg_scalars
+ *                      pick up gamma_new - r.r from scalars[11].               */
 #define SFEM_CG_NSCALARS_NAMED 16 /* [0..16): the named scalars above      */
 #define SFEM_CG_RR_SLOTS 64       /* [16..80): partial sums of gamma_new     */
 #define SFEM_CG_NSCALARS (SFEM_CG_NSCALARS_NAMED + SFEM_CG_RR_SLOTS)
+#define SFEM_CG_MEAN_SUMS (4 * SFEM_CG_RR_SLOTS) /* 2 parities x (1.r, w.r) */
 #define SFEM_CG_STATUS_RUNNING 0.0
 #define SFEM_CG_STATUS_CONVERGED 1.0
 #define SFEM_CG_STATUS_MAXITER 2.0
@@ -532,6 +545,12 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
                      int fuse_rr, int dtype, sfem_stream_t stream);
 int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
                       double* scalars, int dtype, sfem_stream_t stream);
+int sfem_cg_update_r_mean(void* r, const void* ap, const void* w,
+                          int64_t count, double* scalars, double* sums,
+                          int dtype, sfem_stream_t stream);
+int sfem_cg_update_xp_mean(void* x, void* p, const void* r, int64_t count,
+                           double* scalars, double* sums, double total,
+                           int dtype, sfem_stream_t stream);
 /* y = a*x + b*y (plain fused vector update used outside the CG core)         */
 int sfem_axpby(double a, const void* x, double b, void* y, int64_t count,
                int dtype, sfem_stream_t stream);

@@ -21,6 +21,7 @@ SFEM_CG_NSCALARS = 80      # 16 named scalars + 64 partial sums of gamma_new
 CG_STATUS = {0: 'running', 1: 'converged', 2: 'maxiter', 3: 'breakdown_pAp',
              4: 'breakdown_gamma'}
 SFEM_DOT_SLOTS = 1024
+SFEM_CG_MEAN_SUMS = 256    # 2 parities x (64 sums of 1.r + 64 sums of w.r)
 
 c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_void_p)
@@ -115,6 +116,10 @@ SIGNATURES = {
     'sfem_cg_update_p': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_cg_update_r': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_cg_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+    'sfem_cg_update_r_mean': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
+                              c_ptr],
+    'sfem_cg_update_xp_mean': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_dbl,
+                               c_i32, c_ptr],
     'sfem_axpby': [c_dbl, c_ptr, c_dbl, c_ptr, c_i64, c_i32, c_ptr],
     'sfem_stokes_setup': [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
                           c_i32, c_ptr],

@@ -816,6 +816,22 @@ def cg_update_xp(x, p, z, scalars):
         _stream(dev)), 'sfem_cg_update_xp')
 
 
+def cg_update_r_mean(r, ap, w, scalars, sums):
+  dev = _dev(r, ap, w, scalars, sums)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_r_mean(
+        _ptr(r), _ptr(ap), _ptr(w), r.numel(), _ptr(scalars), _ptr(sums),
+        _dtype_code(r), _stream(dev)), 'sfem_cg_update_r_mean')
+
+
+def cg_update_xp_mean(x, p, r, scalars, sums, total):
+  dev = _dev(x, p, r, scalars, sums)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_xp_mean(
+        _ptr(x), _ptr(p), _ptr(r), x.numel(), _ptr(scalars), _ptr(sums),
+        float(total), _dtype_code(x), _stream(dev)), 'sfem_cg_update_xp_mean')
+
+
 def axpby(a, x, b, y):
   """In place: y = a * x + b * y."""
   dev = _dev(x, y)

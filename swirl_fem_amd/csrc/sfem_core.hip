@@ -238,6 +238,31 @@ __device__ inline double block_sum(double v) {
   return total;  // valid on thread 0
 }
 
+// three sums at once (results valid on thread 0)
+__device__ inline void block_sum3(double (&v)[3]) {
+  __shared__ double partial3[3][16];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) partial3[k][wave] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double total = 0.0;
+      for (int w = 0; w < nw; ++w) total += partial3[k][w];
+      v[k] = total;
+    }
+  }
+}
+
 // Streaming vector kernels move 16 bytes per lane per access (dwordx4: the
 // widest, 1 KiB per wave-instruction) with 4 independent accesses in flight per
 // lane; the last < VEC elements are handled by a scalar tail.
@@ -567,6 +592,131 @@ cg_update_xp_kernel(T* __restrict__ x, T* __restrict__ p,
   }
 }
 
+// The same two updates for the preconditioner  M r = r - (w . r / total) 1
+// (the mean projection of the pressure solve, navier_stokes.py:73-78): z = M r
+// is never stored.
+//   update_r_mean : r -= alpha Ap; sums r.r, 1.r and w.r   reads r, Ap, w; writes r
+//   update_xp_mean: c = w.r / total;  gamma_new = r.z = r.r - c 1.r;
+//                   x += alpha p;  p = (r - c) + beta p     reads x, p, r; writes x, p
+// 9 vector passes per iteration instead of 12 (dot, subtraction and the plain
+// updates).  r.r goes to the striped slots of `scalars`; 1.r and w.r to
+// `sums` = 2 sets x (SFEM_CG_RR_SLOTS for 1.r, SFEM_CG_RR_SLOTS for w.r): the
+// set of the iteration's parity is accumulated and read, the other is cleared
+// by update_xp_mean for the next iteration.  scalars[11] receives -c 1.r, which
+// the closing phase adds to gamma_new; scalars[12] = c.
+template <typename T, bool NT>
+__global__ void __launch_bounds__(512)
+cg_update_r_mean_kernel(T* __restrict__ r, const T* __restrict__ ap,
+                        const T* __restrict__ w, int64_t count,
+                        double* __restrict__ scalars,
+                        double* __restrict__ sums) {
+  if (scalars[7] != 0.0) return;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const T alpha = (T)(scalars[0] / scalars[1]);
+  double* set = sums + (((int64_t)scalars[8]) & 1) * (2 * SFEM_CG_RR_SLOTS);
+  const int64_t nvec = count / VN;
+  V* rv = reinterpret_cast<V*>(r);
+  const V* apv = reinterpret_cast<const V*>(ap);
+  const V* wv = reinterpret_cast<const V*>(w);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double rr_acc = 0.0, one_acc = 0.0, w_acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    V rr = ld16<T, NT>(&rv[i]);
+    const V aa = ld16<T, NT>(&apv[i]);
+    const V ww = ld16<T, NT>(&wv[i]);
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* re = reinterpret_cast<T*>(&rr) + c;
+      *re -= alpha * vget<T>(aa, c);
+      const double v = (double)*re;
+      rr_acc += v * v;
+      one_acc += v;
+      w_acc += v * (double)vget<T>(ww, c);
+    }
+    st16<T, NT>(rr, &rv[i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
+    const T rn = r[i] - alpha * ap[i];
+    r[i] = rn;
+    rr_acc += (double)rn * (double)rn;
+    one_acc += (double)rn;
+    w_acc += (double)rn * (double)w[i];
+  }
+  double t[3] = {rr_acc, one_acc, w_acc};
+  block_sum3(t);
+  if (threadIdx.x == 0) {
+    const int q = blockIdx.x & (SFEM_CG_RR_SLOTS - 1);
+    unsafeAtomicAdd(&scalars[SFEM_CG_NSCALARS_NAMED + q], t[0]);
+    unsafeAtomicAdd(&set[q], t[1]);
+    unsafeAtomicAdd(&set[SFEM_CG_RR_SLOTS + q], t[2]);
+  }
+}
+
+template <typename T, bool NT>
+__global__ void __launch_bounds__(512)
+cg_update_xp_mean_kernel(T* __restrict__ x, T* __restrict__ p,
+                         const T* __restrict__ r, int64_t count,
+                         double* __restrict__ scalars,
+                         double* __restrict__ sums, double total) {
+  if (scalars[7] != 0.0) return;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const int par = (int)(((int64_t)scalars[8]) & 1);
+  const double* set = sums + par * (2 * SFEM_CG_RR_SLOTS);
+  double one_r = set[threadIdx.x & 63];
+  double w_r = set[SFEM_CG_RR_SLOTS + (threadIdx.x & 63)];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    one_r += __shfl_xor(one_r, off, 64);
+    w_r += __shfl_xor(w_r, off, 64);
+  }
+  const double mean = w_r / total;
+  const double corr = -mean * one_r;
+  const double gamma_new = cg_gamma_new(scalars) + corr;
+  const T alpha = (T)(scalars[0] / scalars[1]);
+  const T beta = (T)(gamma_new / scalars[0]);
+  const T cm = (T)mean;
+  const int64_t nvec = count / VN;
+  V* xv = reinterpret_cast<V*>(x);
+  V* pv = reinterpret_cast<V*>(p);
+  const V* rv = reinterpret_cast<const V*>(r);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    V xx = ld16<T, NT>(&xv[i]);
+    V pp = ld16<T, NT>(&pv[i]);
+    const V rr = ld16<T, NT>(&rv[i]);
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* xe = reinterpret_cast<T*>(&xx) + c;
+      T* pe = reinterpret_cast<T*>(&pp) + c;
+      *xe += alpha * *pe;
+      *pe = (vget<T>(rr, c) - cm) + beta * *pe;
+    }
+    st16<T, NT>(xx, &xv[i]);
+    st16<T, NT>(pp, &pv[i]);
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < count - nvec * VN) {
+      const int64_t i = nvec * VN + threadIdx.x;
+      const T pi = p[i];
+      x[i] += alpha * pi;
+      p[i] = (r[i] - cm) + beta * pi;
+    }
+    // nobody reads these in this kernel: the correction of gamma_new for the
+    // closing phase, and the other parity's sums for the next iteration
+    if (threadIdx.x == 0) {
+      scalars[11] = corr;
+      scalars[12] = mean;
+    }
+    if (threadIdx.x < 2 * SFEM_CG_RR_SLOTS)
+      sums[(par ^ 1) * (2 * SFEM_CG_RR_SLOTS) + threadIdx.x] = 0.0;
+  }
+}
+
 template <typename T>
 static void launch_update_r(int fuse_rr, bool nt, int grid, hipStream_t stream,
                             T* r, const T* ap, int64_t count, double* scalars) {
@@ -625,6 +775,8 @@ __device__ __forceinline__ void cg_close_iteration(double* scalars,
     g += scalars[SFEM_CG_NSCALARS_NAMED + q];
     scalars[SFEM_CG_NSCALARS_NAMED + q] = 0.0;
   }
+  g += scalars[11];       // r.z - r.r of a fused preconditioner (update_xp_mean)
+  scalars[11] = 0.0;
   scalars[4] = g / scalars[0];
   scalars[0] = g;
   scalars[8] += 1.0;
@@ -716,6 +868,8 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     scalars[2] = 0.0;
     scalars[8] = 0.0;
     scalars[9] = 0.0;
+    scalars[11] = 0.0;
+    scalars[12] = 0.0;
     for (int q = 0; q < SFEM_CG_RR_SLOTS; ++q)
       scalars[SFEM_CG_NSCALARS_NAMED + q] = 0.0;
     scalars[10] = SFEM_CG_STATUS_RUNNING;
@@ -1109,6 +1263,50 @@ int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
                          dim3(stream_grid(count, 512 * 2)), dim3(512), 0,
                          as_stream(stream), (T*)x, (T*)p, (const T*)z, count,
                          scalars);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_update_r_mean(void* r, const void* ap, const void* w,
+                          int64_t count, double* scalars, double* sums,
+                          int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars && sums,
+               "sfem_cg_update_r_mean: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(r && ap && w, "sfem_cg_update_r_mean: null pointer");
+  DISPATCH_DTYPE(dtype, {
+    const int grid = stream_grid(count, 512 * 2);
+    if (streams_past_caches(count, sizeof(T)))
+      hipLaunchKernelGGL((cg_update_r_mean_kernel<T, true>), dim3(grid),
+                         dim3(512), 0, as_stream(stream), (T*)r, (const T*)ap,
+                         (const T*)w, count, scalars, sums);
+    else
+      hipLaunchKernelGGL((cg_update_r_mean_kernel<T, false>), dim3(grid),
+                         dim3(512), 0, as_stream(stream), (T*)r, (const T*)ap,
+                         (const T*)w, count, scalars, sums);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_update_xp_mean(void* x, void* p, const void* r, int64_t count,
+                           double* scalars, double* sums, double total,
+                           int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars && sums && total != 0.0,
+               "sfem_cg_update_xp_mean: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(x && p && r, "sfem_cg_update_xp_mean: null pointer");
+  DISPATCH_DTYPE(dtype, {
+    const int grid = stream_grid(count, 512 * 2);
+    if (streams_past_caches(count, sizeof(T)))
+      hipLaunchKernelGGL((cg_update_xp_mean_kernel<T, true>), dim3(grid),
+                         dim3(512), 0, as_stream(stream), (T*)x, (T*)p,
+                         (const T*)r, count, scalars, sums, total);
+    else
+      hipLaunchKernelGGL((cg_update_xp_mean_kernel<T, false>), dim3(grid),
+                         dim3(512), 0, as_stream(stream), (T*)x, (T*)p,
+                         (const T*)r, count, scalars, sums, total);
   });
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;

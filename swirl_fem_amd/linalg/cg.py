@@ -14,6 +14,11 @@ each iteration; once it fires every later kernel is a no-op, and the host only
 polls the flag every `check_every` iterations.  Iterates and iteration count
 are therefore identical to a loop that tests every iteration.
 
+A preconditioner that offers `mean_projection()` (M r = r - (w.r / total) 1,
+the nullspace projection of the pressure solve) is folded into the two vector
+updates: z = M r is never stored and r . z comes out of the sums update_r takes
+anyway -- 9 vector passes per iteration instead of 12.
+
 Per iteration (M = identity): A(p) with p.Ap fused into the operator's scatter
 stage when it offers `apply_with_dot`; r -= a Ap fused with r.r; then
 x += a p and p = r + b p in one kernel  ->  8 N-vector passes besides the
@@ -21,6 +26,8 @@ apply (SURVEY 8d's fused model: 11; the reference's un-fused loop: 13).
 """
 
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -143,6 +150,19 @@ class CGRunner:
       self.fuse_rr = 2
     self.fold_rr = self.fuse_rr == 2 and (reduce_fn is not None or
                                           interface is not None)
+    # M r = r - (w . r / total) 1 folded into the two vector updates
+    self.mean = None
+    probe = getattr(M, 'mean_projection', None)
+    if (probe is not None and dot_fn is None and reduce_fn is None and
+        interface is None and isinstance(self.r, torch.Tensor) and
+        os.environ.get('SFEM_FUSED_MEAN', '1') != '0'):
+      found = probe()
+      if found is not None:
+        w, total = found
+        self.mean = (layout.flat(layout.like(w.to(self.r.dtype), self.r)),
+                     float(total),
+                     torch.zeros(_lib.SFEM_CG_MEAN_SUMS, dtype=torch.float64,
+                                 device=device))
     self.issued = 0
     self._graph = None
 
@@ -184,6 +204,16 @@ class CGRunner:
       s.dot_into(S.PAP, self.p, Ap, dot_fn, reduce_fn)
     if not merged:
       _ops.cg_scalars(s.t, 0, *args)
+    if self.mean is not None:
+      w, total, sums = self.mean
+      _ops.cg_update_r_mean(layout.flat(self.r),
+                            layout.flat(layout.like(Ap, self.r)), w, s.t, sums)
+      _ops.cg_update_xp_mean(layout.flat(self.x), layout.flat(self.p),
+                             layout.flat(self.r), s.t, sums, total)
+      if not merged:
+        _ops.cg_scalars(s.t, 1, *args)
+      self.issued += 1
+      return
     for rr, aa in zip(_leaves(self.r), _leaves(Ap)):
       _ops.cg_update_r(layout.flat(rr), layout.flat(layout.like(aa, rr)), s.t,
                        self.fuse_rr)

@@ -142,6 +142,32 @@ class _NullspaceProjection:
   def _apply_with_dot(self, r, scalars, slot):
     return _pressure_project_out_nullspace(self.sem, r, (scalars, slot))
 
+  def mean_projection(self):
+    """(w, total) when this preconditioner IS r -> r - (w . r / total) 1 (one
+    partition, pressure nodes inside their elements: QQ^T is the identity), so
+    that `cg` can fold it into its vector updates; else None."""
+    sem = self.sem
+    pmesh = sem.pressure.pspace.mesh
+    gi = pmesh.exchange_gather_indices
+    if (sem.is_partitioned or pmesh.axis_name is not None or
+        pmesh.neighbor_plan is not None or
+        (gi is not None and gi.numel() != 0)):
+      return None
+    _pressure_mass_ones(sem, pmesh.dtype, pmesh.device)
+    b1, total = sem._cache[('pressure_mass_ones', pmesh.dtype)]
+    return b1, float(total)
+
+
+def _pressure_mass_ones(sem, dtype, device):
+  """(B 1, 1 . B 1) of the pressure space, built once."""
+  key = ('pressure_mass_ones', dtype)
+  if key not in sem._cache:
+    ones = torch.ones(sem.pressure.pspace.mesh.num_nodes, dtype=dtype,
+                      device=device)
+    b1 = sem.pressure.B(ones)
+    sem._cache[key] = (b1, sem._global_sum(torch.sum(b1).reshape(1)))
+  return sem._cache[key]
+
 
 def _pressure_project_out_nullspace(sem, p, dot_result=None):
   """Remove the nullspace (all 1s vector) from p."""
@@ -149,11 +175,7 @@ def _pressure_project_out_nullspace(sem, p, dot_result=None):
   # The reference applies the pressure mass matrix twice per call,
   # 1.B(w) / 1.B(1) (:73-78).  B is symmetric, so 1.B(w) = (B 1).w: the
   # vector B 1 is built once and every later call is a dot product.
-  key = ('pressure_mass_ones', p.dtype)
-  if key not in sem._cache:
-    b1 = sem.pressure.B(torch.ones_like(p))
-    sem._cache[key] = (b1, sem._global_sum(torch.sum(b1).reshape(1)))
-  b1, total = sem._cache[key]
+  b1, total = _pressure_mass_ones(sem, p.dtype, p.device)
   if not sem.is_partitioned:
     # one partition: dot and subtraction as two launches, nothing on the host
     if 'project_partials' not in sem._cache:

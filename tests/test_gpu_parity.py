@@ -1012,6 +1012,102 @@ def test_cg_update_groupings_agree(dtype):
       assert float(s2[_lib.SFEM_CG_NSCALARS_NAMED:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_cg_mean_projection_updates(dtype):
+  """sfem_cg_update_r_mean / _xp_mean (z = r - (w.r / total) 1 never stored)
+  against the same arithmetic in torch, two iterations in a row (the sums of
+  the two parities), odd lengths for the scalar tails."""
+  from swirl_fem_amd import _lib, _ops
+  g = torch.Generator(device=DEV).manual_seed(5)
+  tol = 1e-13 if dtype == torch.float64 else 2e-5
+  for n in (2, 7, 1000, 100003):     # (n = 1: the projection leaves nothing)
+    x, r, p = (torch.randn(n, dtype=dtype, device=DEV, generator=g)
+               for _ in range(3))
+    w = torch.rand(n, dtype=dtype, device=DEV, generator=g) + 0.5
+    total = float(w.double().sum())
+    s = torch.zeros(_lib.SFEM_CG_NSCALARS, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(_lib.SFEM_CG_MEAN_SUMS, dtype=torch.float64, device=DEV)
+    gamma = 2.5
+    s[0] = gamma
+    xr, rr, pr = (t.double().clone() for t in (x, r, p))
+    for it in range(3):
+      ap = torch.randn(n, dtype=dtype, device=DEV, generator=g)
+      pap = 1.7 + it
+      s[1] = pap
+      _ops.cg_scalars(s, 0, 10 ** 9, 0.0, 0.0)        # alpha = gamma / p.Ap
+      _ops.cg_update_r_mean(r, ap, w, s, sums)
+      _ops.cg_update_xp_mean(x, p, r, s, sums, total)
+      alpha = gamma / pap
+      rr = rr - alpha * ap.double()
+      c = float((w.double() * rr).sum()) / total
+      z = rr - c
+      gamma_new = float((rr * z).sum())
+      xr = xr + alpha * pr
+      pr = z + (gamma_new / gamma) * pr
+      scale = lambda t: float(t.abs().max()) + 1e-300
+      assert float((r.double() - rr).abs().max()) <= tol * scale(rr)
+      assert float((x.double() - xr).abs().max()) <= tol * scale(xr)
+      assert float((p.double() - pr).abs().max()) <= 50 * tol * (
+          scale(pr) + scale(rr)), (n, it)
+      assert abs(float(s[12]) - c) <= tol * (abs(c) + 1e-300) * n ** 0.5 + 1e-300
+      _ops.cg_scalars(s, 1, 10 ** 9, 0.0, 0.0)        # close: gamma <- r.z
+      assert abs(float(s[0]) - gamma_new) <= 100 * tol * float((rr ** 2).sum())
+      assert float(s[11]) == 0.0
+      gamma = float(s[0])
+      if dtype == torch.float32:        # continue from what the kernels hold
+        xr, rr, pr = (t.double().clone() for t in (x, r, p))
+
+
+def test_cg_folds_the_mean_projection(monkeypatch):
+  """A preconditioner offering `mean_projection()` gives the same iterates,
+  iteration count and solution as the same projection applied as a separate
+  M(r), on the (singular) Neumann stiffness operator; with and without the
+  operator's fused p . Ap and as a graph replay."""
+  from swirl_fem_amd.linalg.cg import cg
+  rp = make_case(3, 3, 5, seed=31)
+  mesh, fes, _ = spaces(rp, 5, 5, 'gll')
+  op = fes.helmholtz_operator(None)
+  w = op.apply(torch.ones(mesh.num_nodes, dtype=torch.float64, device=DEV),
+               1.0, 0.0)                              # B 1
+  total = float(w.sum())
+
+  class Projection:
+    def __call__(self, r):
+      return r - (torch.dot(w, r) / total)
+
+    def mean_projection(self):
+      return w, total
+
+  class Plain:
+    def __call__(self, r):
+      return r - (torch.dot(w, r) / total)
+
+  rng = np.random.default_rng(32)
+  b = dev(rng.standard_normal(mesh.num_nodes))
+  b = b - b.mean()                                     # compatible right side
+  fused_dot = op.linear_operator(0.0, 1.0)
+  assert hasattr(fused_dot, 'apply_with_dot')
+  plain_op = lambda x: op.apply(x, 0.0, 1.0)
+  for A in (fused_dot, plain_op):
+    for tol in (1e-6, 1e-11):
+      x0, i0 = cg(A, b, tol=tol, M=Plain())
+      x1, i1 = cg(A, b, tol=tol, M=Projection(), check_every=5)
+      assert i1['status'] == i0['status'] == 'converged'
+      assert i1['num_iterations'] == i0['num_iterations'], (tol, i0, i1)
+      # (r . z = r.r - c 1.r instead of a sum over r_i z_i: rounding-level
+      # differences, amplified by the conditioning of the Neumann operator)
+      close = 100 * tol + 1e-7
+      assert relerr(x1, x0.cpu().numpy()) < close
+      assert abs(float(i1['residual']) - float(i0['residual'])) <= 1e-2 * float(
+          i0['residual']) + 1e-300
+      x2, i2 = cg(A, b, tol=tol, M=Projection(), graph=True)
+      assert i2['num_iterations'] == i0['num_iterations']
+      assert relerr(x2, x0.cpu().numpy()) < close
+  monkeypatch.setenv('SFEM_FUSED_MEAN', '0')
+  x3, i3 = cg(fused_dot, b, tol=1e-11, M=Projection())
+  assert i3['num_iterations'] == i0['num_iterations']
+
+
 def test_symmetric_solve_is_differentiable_in_b():
   """d/db of <w, A^-1 b> = A^-1 w (adjoint solve with the same operator)."""
   from swirl_fem_amd.linalg.cg import cg, symmetric_solve
