@@ -33,9 +33,12 @@ so = 0 if op.shared_order is None else 2 * op.shared_order.shape[1]
 facet = op.facet_parts is not None and all('facet_table' in q for q in op.facet_parts)
 conn_div = 436 * E if facet else 4 * E * nn
 conn_grad = 436 * E if facet else (4 * nn + so) * E
+# geometry: 24 map coefficients per element, of which the box kernels read 3
+box = facet and all(q['geo_mode'] == operators._GEO_BOX for q in op.facet_parts)
+geo = (3 if box else 24) * s * E
 must = {
-    'stokes_div': conn_div + 3 * s * N + s * N + 24 * s * E + s * E * npp,
-    'stokes_grad_t': conn_grad + s * E * npp + 24 * s * E + 3 * s * N,
+    'stokes_div': conn_div + 3 * s * N + s * N + geo + s * E * npp,
+    'stokes_grad_t': conn_grad + s * E * npp + geo + 3 * s * N,
 }
 def timeit(fn):
   for _ in range(3): fn()
@@ -45,7 +48,7 @@ def timeit(fn):
     a.record(); fn(); b.record()
   torch.cuda.synchronize()
   return sum(a.elapsed_time(b) for a, b in ev) / reps
-res = {'n': n, 'P': P, 'connectivity': 'facet table + chains' if facet else 'index rows', 'velocity_dofs': 3 * N, 'pressure_dofs': E * npp,
+res = {'n': n, 'P': P, 'geometry': 'box' if box else 'affine / multilinear', 'connectivity': 'facet table + chains' if facet else 'index rows', 'velocity_dofs': 3 * N, 'pressure_dofs': E * npp,
        'stokes_div': {'ms': timeit(lambda: op.div(u, scale=scale, out=pout)), 'bytes_must_move': must['stokes_div']},
        'stokes_grad_t': {'ms': timeit(lambda: op.grad_t(p, out=out)), 'bytes_must_move': must['stokes_grad_t']}}
 for k in ('stokes_div', 'stokes_grad_t'):
