@@ -1,7 +1,8 @@
 """Driver for rocprofv3: the fused Stokes divergence / pressure-gradient
 kernels (navier_stokes.py:313-338) on the config-4 GPU block: n^3 elements,
-p = 7 velocity / P - 2 Gauss pressure, component-major velocity, per-node scale
-folded into the divergence (the two kernels of one application of E).
+p = 7 velocity / P - 2 Gauss pressure, component-major velocity, the per-node Q
+of E folded into the pressure gradient and p . E p into the divergence (the two
+kernels of one application of E).
 Prints one JSON line with HIP-event times and the bytes each launch must move.
 env: N (64), P (8), REPS (10)"""
 import json, os, sys
@@ -36,10 +37,22 @@ conn_grad = 436 * E if facet else (4 * nn + so) * E
 # geometry: 24 map coefficients per element, of which the box kernels read 3
 box = facet and all(q['geo_mode'] == operators._GEO_BOX for q in op.facet_parts)
 geo = (3 if box else 24) * s * E
+# the pair as E = D Q D^T issues it (navier_stokes.py:340-348): the per-node Q
+# rides in grad_t (one factor per node), div reads the three components and
+# accumulates p . (D w) for the pressure CG.  PAIR=old: round 2's split
+# (scale in div, none in grad_t)
+old_pair = os.environ.get('PAIR', 'e') == 'old'
 must = {
-    'stokes_div': conn_div + 3 * s * N + s * N + geo + s * E * npp,
-    'stokes_grad_t': conn_grad + s * E * npp + geo + 3 * s * N,
+    'stokes_div': conn_div + 3 * s * N + (s * N if old_pair else s * E * npp) + geo + s * E * npp,
+    'stokes_grad_t': conn_grad + s * E * npp + geo + 3 * s * N + (0 if old_pair else s * N),
 }
+dots = torch.zeros(1024, dtype=torch.float64, device=dev)
+if old_pair:
+  run_div = lambda: op.div(u, scale=scale, out=pout)
+  run_grad = lambda: op.grad_t(p, out=out)
+else:
+  run_div = lambda: op.div(u, out=pout, dot_with=p, dot_out=dots)
+  run_grad = lambda: op.grad_t(p, out=out, scale=scale)
 def timeit(fn):
   for _ in range(3): fn()
   torch.cuda.synchronize()
@@ -49,8 +62,9 @@ def timeit(fn):
   torch.cuda.synchronize()
   return sum(a.elapsed_time(b) for a, b in ev) / reps
 res = {'n': n, 'P': P, 'geometry': 'box' if box else 'affine / multilinear', 'connectivity': 'facet table + chains' if facet else 'index rows', 'velocity_dofs': 3 * N, 'pressure_dofs': E * npp,
-       'stokes_div': {'ms': timeit(lambda: op.div(u, scale=scale, out=pout)), 'bytes_must_move': must['stokes_div']},
-       'stokes_grad_t': {'ms': timeit(lambda: op.grad_t(p, out=out)), 'bytes_must_move': must['stokes_grad_t']}}
+       'pair': 'round 2 (scale in div)' if old_pair else 'as E issues it (Q in grad_t, p . Dw in div)',
+       'stokes_div': {'ms': timeit(run_div), 'bytes_must_move': must['stokes_div']},
+       'stokes_grad_t': {'ms': timeit(run_grad), 'bytes_must_move': must['stokes_grad_t']}}
 for k in ('stokes_div', 'stokes_grad_t'):
   res[k]['frac_of_8TBs'] = res[k]['bytes_must_move'] / (res[k]['ms'] * 1e-3) / 8e12
 print(json.dumps(res))
