@@ -6,7 +6,8 @@
  *   stiffness of a constant = 0, mass of a constant sums to the volume,
  *   sfem_dot, error reporting through sfem_last_error(); the fused apply also
  *   through the compact connectivity (sfem_facet_table_build,
- *   sfem_helmholtz_setup_affine, facet table + chains, box and affine).
+ *   sfem_helmholtz_setup_affine, facet table + chains, box and affine);
+ *   one CG update with the mean projection folded in against host arithmetic.
  * Exit code 0 = all good; prints the failing check otherwise. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -297,6 +298,55 @@ int main(void) {
     /* SFEM_GEO_BOX without a facet table is refused */
     a.facet_table = NULL; a.geo_mode = SFEM_GEO_BOX;
     CHECK(sfem_helmholtz_apply(&a, NULL) != SFEM_OK, "box without table");
+  }
+  /* --- CG updates with the mean projection folded in (navier_stokes.py:73-78,
+   * linalg/cg.py:75-86): r -= a Ap; z = r - (w.r / total) 1; p = z + b p      */
+  {
+    enum { M = 1000 };
+    static double x[M], r[M], p[M], ap[M], w[M], xr[M], rr[M], pr[M];
+    double total = 0.0;
+    for (int k = 0; k < M; ++k) {
+      x[k] = sin(0.3 * k); r[k] = cos(0.7 * k) + 0.25; p[k] = sin(1.1 * k + 1.0);
+      ap[k] = cos(0.2 * k * k); w[k] = 1.0 + 0.5 * sin(0.05 * k);
+      total += w[k];
+    }
+    double scal[SFEM_CG_NSCALARS] = {0}, sums[SFEM_CG_MEAN_SUMS] = {0};
+    const double gamma = 2.5, pap = 1.75, alpha = gamma / pap;
+    scal[0] = gamma; scal[1] = pap;
+    double *dx = (double*)to_device(x, sizeof x), *dr = (double*)to_device(r, sizeof r);
+    double *dp = (double*)to_device(p, sizeof p), *dap = (double*)to_device(ap, sizeof ap);
+    double *dw = (double*)to_device(w, sizeof w);
+    double *dsc = (double*)to_device(scal, sizeof scal);
+    double *dsm = (double*)to_device(sums, sizeof sums);
+    CHECK(dx && dr && dp && dap && dw && dsc && dsm, "device buffers");
+    CHECK(sfem_cg_scalars(dsc, 0, 1e9, 0.0, 0.0, NULL, NULL) == SFEM_OK, "%s",
+          sfem_last_error());
+    CHECK(sfem_cg_update_r_mean(dr, dap, dw, M, dsc, dsm, SFEM_F64, NULL) ==
+              SFEM_OK, "%s", sfem_last_error());
+    CHECK(sfem_cg_update_xp_mean(dx, dp, dr, M, dsc, dsm, total, SFEM_F64,
+                                 NULL) == SFEM_OK, "%s", sfem_last_error());
+    CHECK(sfem_cg_scalars(dsc, 1, 1e9, 0.0, 0.0, NULL, NULL) == SFEM_OK, "%s",
+          sfem_last_error());
+    double wr = 0.0, rz = 0.0;
+    for (int k = 0; k < M; ++k) { rr[k] = r[k] - alpha * ap[k]; wr += w[k] * rr[k]; }
+    const double c = wr / total;
+    for (int k = 0; k < M; ++k) rz += rr[k] * (rr[k] - c);
+    for (int k = 0; k < M; ++k) {
+      xr[k] = x[k] + alpha * p[k];
+      pr[k] = (rr[k] - c) + (rz / gamma) * p[k];
+    }
+    HIP(hipMemcpy(x, dx, sizeof x, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(r, dr, sizeof r, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(p, dp, sizeof p, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(scal, dsc, sizeof scal, hipMemcpyDeviceToHost));
+    for (int k = 0; k < M; ++k)
+      CHECK(fabs(x[k] - xr[k]) < 1e-13 && fabs(r[k] - rr[k]) < 1e-13 &&
+                fabs(p[k] - pr[k]) < 1e-12,
+            "mean-projection CG update at %d", k);
+    CHECK(fabs(scal[0] - rz) < 1e-10 * fabs(rz) && scal[8] == 1.0,
+          "closed iteration: gamma = r.z (%.17g vs %.17g)", scal[0], rz);
+    CHECK(sfem_cg_update_xp_mean(dx, dp, dr, M, dsc, dsm, 0.0, SFEM_F64, NULL) !=
+              SFEM_OK, "total = 0 is refused");
   }
   HIP(hipDeviceSynchronize());
   printf("c-abi OK\n");
