@@ -31,5 +31,5 @@ def t(fn, n=50):
   torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / n
 u = us[-1]; p = ps[-1]
 print(json.dumps({'C': t(lambda: sem.C(u)), 'B': t(lambda: sem.B(u)), 'D': t(lambda: sem.D(u)),
-                  'Dt': t(lambda: sem.Dt(p)), 'E': t(lambda: sem.E(p)), 'A': t(lambda: sem.A(u)),
+                  'Dt': t(lambda: sem.Dt(p)), 'E': t(lambda: sem.E(p, cfg.dt, 3)), 'A': t(lambda: sem.A(u)),
                   'filter': t(lambda: sem.filter(u, 0.05)) if hasattr(sem, 'filter') else None}))

@@ -166,6 +166,46 @@ class CGRunner:
     self.issued = 0
     self._graph = None
 
+  def matches(self, b, tol, atol, maxiter) -> bool:
+    """Whether `restart(b)` can take this right-hand side: same leaves
+    (shape, dtype, device, memory layout) and the same stopping rule (a
+    captured iteration carries tol / atol / maxiter as kernel arguments)."""
+    mine, theirs = _leaves(self.r), _leaves(b)
+    if len(mine) != len(theirs) or (tol, atol) != (self.tol, self.atol):
+      return False
+    if maxiter is None:
+      maxiter = 10 * sum(l.numel() for l in theirs)
+    if maxiter != self.maxiter:
+      return False
+    return all(isinstance(t, torch.Tensor) and t.shape == m.shape and
+               t.dtype == m.dtype and t.device == m.device
+               for m, t in zip(mine, theirs))
+
+  def restart(self, b, x0=None):
+    """The same solve (A, M, stopping rule) for a new right-hand side: x, r,
+    p and the scalars are rewritten IN PLACE, so an iteration captured into a
+    HIP graph stays valid -- a time stepper that solves with the same
+    operators every step then records each of them once (recording costs
+    about 1 ms per solve, a third of a Kolmogorov-generator step)."""
+    s, S = self.s, _Scalars
+    if x0 is None:
+      _map(lambda xx: xx.zero_(), self.x)
+    else:
+      _map(lambda xx, t: xx.copy_(layout.like(t, xx)), self.x, x0)
+    s.dot_into(S.BB, b, b, self.dot_fn, self.reduce_fn, self.interface)
+    _map(lambda rr, bb, ax: rr.copy_(layout.like(bb, rr) - layout.like(ax, rr)),
+         self.r, b, self.A(self.x))
+    z = self.r if self.identity_m else self.M(self.r)
+    if z is not self.r:
+      _map(lambda pp, zz: pp.copy_(layout.like(zz, pp)), self.p, z)
+    else:
+      _map(lambda pp, rr: pp.copy_(rr), self.p, self.r)
+    s.dot_into(S.GAMMA, self.r, z, self.dot_fn, self.reduce_fn, self.interface)
+    _ops.cg_scalars(s.t, 2, self.maxiter, self.tol, self.atol, self.parts)
+    if self.mean is not None:
+      self.mean[2].zero_()
+    self.issued = 0
+
   def step(self):
     """One iteration of cg.py:75-86, all on the device."""
     if self._graph is not None:
@@ -311,7 +351,7 @@ class CGRunner:
 
 def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
        dot_fn=None, reduce_fn=None, interface=None, check_every=16,
-       graph=False):
+       graph=False, workspace=None, key=None):
   """Solves A x = b with (preconditioned) conjugate gradients.
 
   Args:
@@ -336,15 +376,29 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
       worth it when an iteration is launch-bound (small meshes, long solves).
       `A` and `M` must then be pure device work on fixed operands.
     check_every: the host polls the device convergence flag this often.
+    workspace, key: with `graph=True`, a dict owned by the caller and a
+      hashable key that stands for (A, M): the solver state and the recorded
+      iteration are kept under `workspace[key]` and reused by later calls with
+      the same key, stopping rule and vector shapes (`CGRunner.restart`).  The
+      caller promises that A and M of those calls are the same operators.
   Returns:
     (x, info) with info = {'residual': gamma, 'num_iterations': k,
     'status': 'converged' | 'maxiter' | 'breakdown_gamma' | 'breakdown_pAp'}.
   """
   if not _leaves(b):
     return b, {'residual': 0.0, 'num_iterations': 0, 'status': 'converged'}
-  run = CGRunner(A, b, x0, tol=tol, atol=atol, maxiter=maxiter, M=M,
-                 dot_fn=dot_fn, reduce_fn=reduce_fn, interface=interface)
-  if graph and dot_fn is None and run.maxiter > 2 and not run.done():
+  reuse = (graph and workspace is not None and key is not None and
+           dot_fn is None and reduce_fn is None and interface is None)
+  run = workspace.get(key) if reuse else None
+  if run is not None and run.matches(b, tol, atol, maxiter):
+    run.restart(b, x0)
+  else:
+    run = CGRunner(A, b, x0, tol=tol, atol=atol, maxiter=maxiter, M=M,
+                   dot_fn=dot_fn, reduce_fn=reduce_fn, interface=interface)
+    if reuse:
+      workspace[key] = run
+  if (graph and dot_fn is None and run.maxiter > 2 and run._graph is None and
+      not run.done()):
     run.capture()
   while run.issued < run.maxiter:
     for _ in range(min(check_every, run.maxiter - run.issued)):
@@ -360,7 +414,8 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
                   f"{info['num_iterations']} iterations: x is the last "
                   'iterate, not a solution to the requested tolerance',
                   RuntimeWarning, stacklevel=2)
-  return run.x, info
+  # (a kept runner overwrites its x in the next solve)
+  return (_map(lambda t: t.clone(), run.x) if reuse else run.x), info
 
 
 class _SymmetricSolve(torch.autograd.Function):

@@ -641,7 +641,9 @@ class StokesSEM:
                       project_out_nullspace=True, tol: float = 1e-8,
                       atol: float = 0) -> tuple[torch.Tensor, torch.Tensor, Any]:
     """Evolves the Stokes system by one fractional step (reference :350-458)."""
-    if pressure_preconditioner is None and project_out_nullspace:
+    default_projection = pressure_preconditioner is None and \
+        project_out_nullspace
+    if default_projection:
       pressure_preconditioner = _NullspaceProjection(self)
 
     ext_coeffs = extk_coeffs(k=1)
@@ -670,8 +672,17 @@ class StokesSEM:
       # f and u_star vanish on the Dirichlet rows; saying so to autograd keeps
       # the cotangent solve on the same (masked) system
       f = self.velocity.interior_mask * f
+    # the two solves of a step use the same operators step after step: their
+    # recorded iterations are kept (SFEM_GRAPH_REUSE=0: record every solve)
+    if (graph and not diff and self._reduce_fn() is None and
+        os.environ.get('SFEM_GRAPH_REUSE', '1') != '0'):
+      ws = self._cache.setdefault('cg_workspaces', {})
+      keep = lambda *key: dict(workspace=ws, key=key + (tol, atol))
+    else:
+      keep = lambda *key: {}
     u_star, info = _solve(diff, H_, f, M=self.velocity.exchange, tol=tol,
-                          atol=atol, graph=graph, reduce_fn=self._reduce_fn())
+                          atol=atol, graph=graph, reduce_fn=self._reduce_fn(),
+                          **keep('H', beta_k / dt, float(mu)))
     if diff:
       u_star = self.velocity.interior_mask * u_star
     if u_boundary is not None:
@@ -682,7 +693,9 @@ class StokesSEM:
 
     dp, info = _solve(diff, _PressureOperator(self, dt, time_order),
                       -self.D(u_star), M=pressure_preconditioner, tol=tol,
-                      atol=atol, graph=graph, reduce_fn=self._reduce_fn())
+                      atol=atol, graph=graph, reduce_fn=self._reduce_fn(),
+                      **(keep('E', float(dt), int(time_order))
+                         if default_projection else {}))
     aux['dp_info'] = info
 
     u = u_star + self.Q(self.Dt(dp), dt=dt, time_order=time_order)

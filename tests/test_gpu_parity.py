@@ -1111,6 +1111,45 @@ def test_cg_folds_the_mean_projection(monkeypatch):
   assert abs(i3['num_iterations'] - i0['num_iterations']) <= 2
 
 
+def test_cg_runner_reuse_keeps_the_recorded_iteration():
+  """`cg(..., graph=True, workspace=ws, key=k)`: the second and third solve
+  with the same key restart the kept runner (no new recording) and return what
+  a fresh solve returns; a different stopping rule or shape builds a new one."""
+  from swirl_fem_amd.linalg import cg as cgmod
+  from swirl_fem_amd.linalg.cg import cg
+  rp = make_case(3, 3, 5, seed=41)
+  mesh, fes, _ = spaces(rp, 5, 5, 'gll')
+  bmask = mesh.physical_masks['boundary']
+  op = fes.helmholtz_operator(bmask)
+  A = op.linear_operator(0.3, 1.0)
+  interior = (~bmask).to(torch.float64)
+  rng = np.random.default_rng(42)
+  bs = [interior * dev(rng.standard_normal(mesh.num_nodes)) for _ in range(3)]
+  ws = {}
+  captures = []
+  orig = cgmod.CGRunner.capture
+  cgmod.CGRunner.capture = lambda self: (captures.append(1), orig(self))[1]
+  try:
+    for k, b in enumerate(bs):
+      x0 = None if k < 2 else 0.5 * bs[0]
+      want, iw = cg(A, b, x0, tol=1e-9)
+      got, ig = cg(A, b, x0, tol=1e-9, graph=True, workspace=ws, key='A')
+      assert ig['status'] == 'converged'
+      assert ig['num_iterations'] == iw['num_iterations']
+      assert relerr(got, want.cpu().numpy()) < 1e-9
+      assert len(ws) == 1 and len(captures) == 1, (k, len(ws), captures)
+    first = ws['A']
+    assert got.data_ptr() != first.x.data_ptr()      # a copy: x is reused
+    # another stopping rule: a new runner under the same key
+    cg(A, bs[0], tol=1e-6, graph=True, workspace=ws, key='A')
+    assert ws['A'] is not first and len(captures) == 2
+    # without a key nothing is kept
+    cg(A, bs[0], tol=1e-6, graph=True, workspace=ws)
+    assert len(ws) == 1 and len(captures) == 3
+  finally:
+    cgmod.CGRunner.capture = orig
+
+
 def test_symmetric_solve_is_differentiable_in_b():
   """d/db of <w, A^-1 b> = A^-1 w (adjoint solve with the same operator)."""
   from swirl_fem_amd.linalg.cg import cg, symmetric_solve
