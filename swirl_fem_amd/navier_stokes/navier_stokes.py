@@ -654,6 +654,13 @@ class StokesSEM:
     bdf = bdfk_coeffs(time_order)
     beta_hist, beta_k = bdf[:-1], float(bdf[-1])
     H_ = lambda u: self.H(u, beta_k / dt, mu)
+    fused_h = self._masked_operator()
+    if fused_h is not None and not autodiff.needs_grad(f, u_boundary, *us,
+                                                       *ps):
+      # the same apply as an object `cg` can ask for p . H p (accumulated in
+      # the kernel's scatter stage: one dot pass and one scalar launch less
+      # per iteration)
+      H_ = fused_h.linear_operator(beta_k / dt, float(mu))
     f = f - self.B((1 / dt) * sum(float(c) * u for c, u in zip(beta_hist, us)))
     if u_boundary is not None:
       f = f - H_(u_boundary)
