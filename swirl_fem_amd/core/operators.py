@@ -628,6 +628,7 @@ class StokesDivGrad:
   # the launches on compact connectivity + chains (component-major fields,
   # 3D, P = 6..8: `csrc/sfem_stokes_facet.h`), or None
   facet_parts: list | None = None
+  _div_parts: list | None = None      # what `div` launches, see `_parts_for`
 
   @classmethod
   def create(cls, vspace, pspace, dirichlet_mask=None,
@@ -731,11 +732,25 @@ class StokesDivGrad:
         out.append(new)
     return out
 
-  def _parts_for(self, field):
-    """Facet / chain launches for component-major fields."""
-    if self.facet_parts is not None and _ops.is_component_major(field):
+  def _parts_for(self, field, div=False):
+    """Facet / chain launches for component-major fields.  The divergence
+    takes them for box elements only: its general-geometry chain kernels hold
+    three gathered components next to nine cofactors per point and spill
+    (multilinear, 48^3 elements: 1.98 ms against 0.62 for the index-row kernel;
+    affine with the fused dot 0.61 against 0.56), while `grad_t`, whose cost is
+    the shared-node atomics, gains a quarter from the chains on every geometry
+    (`scripts/time_stokes_jitter.py`).  `SFEM_STOKES_FACET_DIV=all` sends the
+    divergence through them regardless (tests)."""
+    if self.facet_parts is None or not _ops.is_component_major(field):
+      return self.parts
+    if not div or os.environ.get('SFEM_STOKES_FACET_DIV', 'box') == 'all':
       return self.facet_parts
-    return self.parts
+    if self._div_parts is None:
+      self._div_parts = [
+          q if q['geo_mode'] == _GEO_BOX or 'facet_table' not in q else
+          {k: v for k, v in q.items() if k not in ('facet_table', 'chains')}
+          for q in self.facet_parts]
+    return self._div_parts
 
   @staticmethod
   def _order(mesh, enc):
@@ -821,7 +836,8 @@ class StokesDivGrad:
       dot_with = dot_with.to(u.dtype).contiguous()
       if tuple(dot_with.shape) != (self.num_pressure_nodes,):
         raise ValueError('dot_with must be a pressure vector')
-    return _ops.stokes_div(u, out, self.enc, self.penc, self._parts_for(u),
+    return _ops.stokes_div(u, out, self.enc, self.penc,
+                           self._parts_for(u, div=True),
                            self.host, mesh.ndim, mesh.gridpoints_1d.num_points,
                            scale, dot_with, dot_out)
 
