@@ -263,6 +263,7 @@ class HelmholtzOperator:
   # the same launches on compact connectivity (scalar / component-major
   # fields), or None: see `_facet_parts`
   facet_parts: list | None = None
+  _vector_parts: list | None = None   # launches of vector fields (`_parts_for`)
 
   @classmethod
   def create(cls, fespace, dirichlet_mask=None, geometry='auto',
@@ -430,7 +431,8 @@ class HelmholtzOperator:
             self.fespace.mesh.assembly_plan().multiplicity, parts)
       facet = (None if self.facet_parts is None
                else restrict(self.facet_parts, keep))
-      halves.append(dataclasses.replace(self, parts=parts, facet_parts=facet))
+      halves.append(dataclasses.replace(self, parts=parts, facet_parts=facet,
+                                        _vector_parts=None))
     return tuple(halves)
 
   def apply(self, u, lambda0=0.0, lambda1=1.0, out=None, *, zero=True,
@@ -459,10 +461,31 @@ class HelmholtzOperator:
   def _parts_for(self, u):
     """Facet-table launches for scalar / component-major fields (the kernels
     address node n of component k at n + k * stride), index rows otherwise."""
-    if self.facet_parts is not None and (
+    if self.facet_parts is None or not (
         u.dim() == 1 or u.shape[-1] == 1 or _ops.is_component_major(u)):
+      return self.parts
+    if u.dim() == 1 or u.shape[-1] == 1:
       return self.facet_parts
-    return self.parts
+    # Vector fields walk the chains component by component: the geometry is
+    # evaluated once per component, which is nothing for box / affine /
+    # multilinear elements (48^3, 3 components: 0.77 / 1.21 ms against 1.47 /
+    # 2.63 on index rows) but re-reads the stored factors of curved elements
+    # three times (2.57 against 2.10 ms): those stay on the index rows in
+    # fp64 and on the one-element facet kernel in fp32 (1.14 against 1.23 /
+    # 1.32 ms) -- scripts/sweep_vector_fields.py.
+    if self._vector_parts is None:
+      if not any(q['geo_mode'] == _GEO_POINT and 'facet_table' in q
+                 for q in self.facet_parts):
+        self._vector_parts = self.facet_parts
+      elif self.fespace.dtype == torch.float64:
+        self._vector_parts = (
+            [q for q in self.facet_parts if q['geo_mode'] != _GEO_POINT] +
+            [q for q in self.parts if q['geo_mode'] == _GEO_POINT])
+      else:
+        self._vector_parts = [
+            {k: v for k, v in q.items() if k != 'chains'}
+            if q['geo_mode'] == _GEO_POINT else q for q in self.facet_parts]
+    return self._vector_parts
 
   def apply_local(self, u_local, lambda0=0.0, lambda1=1.0):
     """Element-local action (E, n[, nc]) -> (E, n[, nc]); no gather/scatter."""
