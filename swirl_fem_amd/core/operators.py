@@ -584,7 +584,18 @@ def supports_fused_stokes(vspace, pspace) -> str | None:
   sample = torch.unique(torch.linspace(
       0, max(E - 1, 0), steps=min(E, 512), device=vspace.device).round().long())
   jv, jp = _sample_jacdets(vspace, sample), _sample_jacdets(pspace, sample)
-  tol = 1e-10 if jv.dtype == torch.float64 else 1e-4
+  # what rounding alone does to det J: the nodal coordinates carry eps |x|,
+  # differentiating them over an element of size h with P points amplifies
+  # that by ~ P^2 |x| / h (fp32, 40 elements across a unit cube, P = 8: 1.5e-4)
+  ndim = vspace.mesh.ndim
+  if jv.numel():
+    h = 2.0 * float(jv.abs().amax()) ** (1.0 / ndim)
+    xmax = float(vspace.mesh.node_coords.abs().amax())
+    P = vspace.mesh.gridpoints_1d.num_points
+    rounding = 32 * torch.finfo(jv.dtype).eps * P * P * max(xmax / h, 1.0)
+  else:
+    rounding = 0.0
+  tol = max(1e-10 if jv.dtype == torch.float64 else 1e-4, rounding)
   if jv.shape != jp.shape or not bool(
       ((jv - jp).abs() <= tol * jv.abs().amax()).all()):
     return 'velocity and pressure spaces carry different geometry'
@@ -769,10 +780,17 @@ class StokesDivGrad:
     if not div or os.environ.get('SFEM_STOKES_FACET_DIV', 'box') == 'all':
       return self.facet_parts
     if self._div_parts is None:
+      # (fp32: the box divergence measures 0.20 against 0.18 ms on index rows
+      # at 40^3, so it keeps them too -- scripts/sweep_stokes_facet_vs_rows.py)
+      box_ok = self.vspace.dtype == torch.float64
+      def rows(q):      # the same elements from their index rows
+        q = {k: v for k, v in q.items() if k not in ('facet_table', 'chains')}
+        if q['geo_mode'] == _GEO_BOX:
+          q['geo_mode'] = _GEO_AFFINE
+        return q
       self._div_parts = [
-          q if q['geo_mode'] == _GEO_BOX or 'facet_table' not in q else
-          {k: v for k, v in q.items() if k not in ('facet_table', 'chains')}
-          for q in self.facet_parts]
+          q if (q['geo_mode'] == _GEO_BOX and box_ok) or
+          'facet_table' not in q else rows(q) for q in self.facet_parts]
     return self._div_parts
 
   @staticmethod

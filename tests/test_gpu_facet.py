@@ -306,6 +306,8 @@ def test_stokes_box_kernels_match_index_rows(order, periodic, dtype,
                 periodic_dims=periodic)
   bcs = {} if len(periodic) == 3 else {'boundary': (1, 0.0)}
   monkeypatch.setenv('SFEM_CHAIN_LEN', '3')
+  # (by default the divergence walks chains on fp64 box elements only)
+  monkeypatch.setenv('SFEM_STOKES_FACET_DIV', 'all')
 
   def build(**env):
     for k, v in env.items():
