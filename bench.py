@@ -288,6 +288,13 @@ def main():
                      '(use --dry-run to rehearse the launch on CPU)')
   if args.backend == 'gloo':
     local_rank %= torch.cuda.device_count()
+  if local_rank >= torch.cuda.device_count():
+    print(f'bench.py: rank {rank} of {world} needs GPU {local_rank}, but this '
+          f'process sees {torch.cuda.device_count()} device(s) '
+          f'(HIP_VISIBLE_DEVICES={os.environ.get("HIP_VISIBLE_DEVICES")}); '
+          'one rank per GPU over RCCL -- `--backend gloo` lets ranks share a '
+          'device for a rehearsal', file=sys.stderr, flush=True)
+    raise SystemExit(3)
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:
