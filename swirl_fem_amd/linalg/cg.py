@@ -59,6 +59,9 @@ def _as_vec(t):
   return t
 
 
+MAX_KEPT_RUNNERS = 6   # solver states a `workspace` of `cg` holds at most
+
+
 class _Scalars:
   """Device-resident CG scalars (see include/sfem.h, SFEM_CG_NSCALARS)."""
   GAMMA, PAP, GAMMA_NEW, ALPHA, BETA, BB, ATOL2, DONE, ITERS = range(9)
@@ -396,7 +399,12 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
     run = CGRunner(A, b, x0, tol=tol, atol=atol, maxiter=maxiter, M=M,
                    dot_fn=dot_fn, reduce_fn=reduce_fn, interface=interface)
     if reuse:
+      workspace.pop(key, None)
       workspace[key] = run
+      # (a stepper whose coefficients change every step must not collect
+      # solver states without bound: the oldest ones go)
+      while len(workspace) > MAX_KEPT_RUNNERS:
+        workspace.pop(next(iter(workspace)))
   if (graph and dot_fn is None and run.maxiter > 2 and run._graph is None and
       not run.done()):
     run.capture()

@@ -1146,6 +1146,10 @@ def test_cg_runner_reuse_keeps_the_recorded_iteration():
     # without a key nothing is kept
     cg(A, bs[0], tol=1e-6, graph=True, workspace=ws)
     assert len(ws) == 1 and len(captures) == 3
+    # a stepper with ever-changing coefficients does not pile up states
+    for k in range(cgmod.MAX_KEPT_RUNNERS + 3):
+      cg(A, bs[0], tol=1e-3, graph=True, workspace=ws, key=('dt', k))
+    assert len(ws) == cgmod.MAX_KEPT_RUNNERS and 'A' not in ws
   finally:
     cgmod.CGRunner.capture = orig
 
