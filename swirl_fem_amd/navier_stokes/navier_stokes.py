@@ -687,9 +687,18 @@ class StokesSEM:
       keep = lambda *key: dict(workspace=ws, key=key + (tol, atol))
     else:
       keep = lambda *key: {}
+    # (replaying an iteration pays while it is launch-bound; on vectors of
+    # tens of millions of values there is nothing to save -- 64^3 elements,
+    # p = 7: 2.14 against 2.20 s per step eager on one box, equal within the
+    # noise on another -- and the eager loop does not hold a second set of
+    # solver vectors)
+    limit = int(os.environ.get('SFEM_GRAPH_MAX_NUMEL', str(1 << 25)))
+    small = lambda b: graph and b.numel() <= limit
     u_star, info = _solve(diff, H_, f, M=self.velocity.exchange, tol=tol,
-                          atol=atol, graph=graph, reduce_fn=self._reduce_fn(),
-                          **keep('H', beta_k / dt, float(mu)))
+                          atol=atol, graph=small(f),
+                          reduce_fn=self._reduce_fn(),
+                          **(keep('H', beta_k / dt, float(mu))
+                             if small(f) else {}))
     if diff:
       u_star = self.velocity.interior_mask * u_star
     if u_boundary is not None:
@@ -698,11 +707,12 @@ class StokesSEM:
 
     u_star = self.filter(u_star, alpha=alpha)
 
-    dp, info = _solve(diff, _PressureOperator(self, dt, time_order),
-                      -self.D(u_star), M=pressure_preconditioner, tol=tol,
-                      atol=atol, graph=graph, reduce_fn=self._reduce_fn(),
+    rhs = -self.D(u_star)
+    dp, info = _solve(diff, _PressureOperator(self, dt, time_order), rhs,
+                      M=pressure_preconditioner, tol=tol, atol=atol,
+                      graph=small(rhs), reduce_fn=self._reduce_fn(),
                       **(keep('E', float(dt), int(time_order))
-                         if default_projection else {}))
+                         if default_projection and small(rhs) else {}))
     aux['dp_info'] = info
 
     u = u_star + self.Q(self.Dt(dp), dt=dt, time_order=time_order)
