@@ -240,9 +240,19 @@ def main():
                        '(N=8: 2x2x2 blocks; along a direction with one block '
                        'the images are summed on the rank itself); solves the '
                        'Helmholtz problem B + A instead of the singular A')
-  ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+  ap.add_argument('--backend', default='nccl',
+                  choices=['nccl', 'gloo', 'threads'],
                   help="'gloo' rehearses the N>1 path with all ranks on the "
-                       'visible GPU(s) (interface buffers staged via host)')
+                       'visible GPU(s) (interface buffers staged via host); '
+                       "'threads' runs the N ranks as threads of ONE process "
+                       'on one GPU (distributed/inprocess.py: the 2x2x2 layout '
+                       'of --gpus 8 on a one-GPU box, whose process limit '
+                       'rules out eight gloo ranks); neither is a measurement')
+  ap.add_argument('--verify', action='store_true',
+                  help='after the timed iterations, solve A x = A x* for a '
+                       'manufactured x* through the same operator and solver '
+                       'and report max |x - x*| / max |x*| over all ranks in '
+                       'config.verify')
   ap.add_argument('--partitioned', default='consistent',
                   choices=['consistent', 'reference'],
                   help="N>1 CG formulation: consistent vectors with the "
@@ -262,6 +272,11 @@ def main():
                        'runs (the kernels have no CPU path)')
   args = ap.parse_args()
 
+  if args.backend == 'threads' and args.gpus > 1:
+    if args.dry_run:
+      raise SystemExit('bench.py: --dry-run rehearses process ranks; '
+                       '--backend threads has none')
+    return run_threads(args)
   world_env = os.environ.get('WORLD_SIZE')
   if world_env is None and args.gpus > 1:
     # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh
@@ -279,9 +294,6 @@ def main():
 
   import torch
   import torch.distributed as dist
-  from swirl_fem_amd.core.fespace import FiniteElementSpace
-  from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
-  from swirl_fem_amd.linalg.cg import CGRunner
 
   if not torch.cuda.is_available():
     raise SystemExit('bench.py: no GPU visible; the kernels have no CPU path '
@@ -316,6 +328,43 @@ def main():
             f'MASTER_PORT={os.environ.get("MASTER_PORT")}) could not join the '
             f'process group: {exc!r}', file=sys.stderr, flush=True)
       raise SystemExit(3)
+  rank_main(args, world, rank, device)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def run_threads(args):
+  """`--backend threads`: the N ranks as threads of this process on cuda:0."""
+  import torch
+  from swirl_fem_amd.distributed import inprocess
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py: no GPU visible; the kernels have no CPU path')
+  torch.cuda.set_device(0)
+  device = torch.device('cuda', 0)
+  world = inprocess.ThreadWorld(args.gpus)
+  world.run(lambda rank: rank_main(args, args.gpus, rank, device))
+  return 0
+
+
+def manufactured_solution(mesh, periodic):
+  """x*: smooth, zero on the Dirichlet boundary of the unit cube (or periodic
+  on it), a function of the coordinates -- so equal on every holder of a node."""
+  import torch
+  x = mesh.node_coords
+  k = 2.0 * np.pi if periodic else np.pi
+  xs = torch.sin(k * x[:, 0]) * torch.sin(k * x[:, 1]) * torch.sin(k * x[:, 2])
+  if periodic:
+    xs = xs + torch.cos(k * x[:, 0])
+  return xs
+
+
+def rank_main(args, world, rank, device):
+  """One rank of the benchmark (a process, or a thread of `run_threads`)."""
+  import torch
+  from swirl_fem_amd.core.fespace import FiniteElementSpace
+  from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
+  from swirl_fem_amd.distributed import comm
+  from swirl_fem_amd.linalg.cg import CGRunner
 
   P = args.p + 1
   grid = Nodes1D.create(P, NodeType.GAUSS_LOBATTO_LEGENDRE)
@@ -384,7 +433,7 @@ def main():
   def barrier():
     torch.cuda.synchronize()
     if world > 1:
-      dist.barrier()
+      comm.barrier()
     torch.cuda.synchronize()
 
   for _ in range(args.warmup):
@@ -397,8 +446,7 @@ def main():
   elapsed = time.perf_counter() - t0
   if world > 1:
     tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
+    elapsed = float(comm.all_reduce_max_(tt).item())
   ms_per_step = 1e3 * elapsed / args.steps
   value = N_global / (elapsed / args.steps) / 1e9
 
@@ -448,8 +496,7 @@ def main():
     exchange_ms = s0.elapsed_time(s1) / args.steps
     mine = torch.tensor([apply_ms, exchange_ms, float(part.plan.num_shared)],
                         dtype=torch.float64, device=device)
-    every = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(every, mine)
+    every = comm.all_gather(mine)
     per_rank = {'apply_ms': [float(t[0]) for t in every],
                 'exchange_ms': [float(t[1]) for t in every],
                 'interface_values': [int(t[2]) for t in every]}
@@ -498,6 +545,31 @@ def main():
                     'ms_per_step': ref[0], 'source': ref[1],
                     'speedup_vs_strong_ref': ref[0] / ms_per_step}
 
+  verify = None
+  if args.verify:
+    # A x = A x* through the operator and solver that were just timed
+    xs = manufactured_solution(mesh, bool(periodic_dims)).to(tdtype)
+    if 'boundary' in mesh.physical_masks:
+      xs = xs * (~mesh.physical_masks['boundary']).to(tdtype)
+    vtol = 1e-10 if args.dtype == 'f64' else 1e-5
+    if world > 1 and args.partitioned == 'consistent':
+      from swirl_fem_amd.distributed import solver
+      xv, vinfo = solver.cg(A, A(xs).clone(), part.plan, tol=vtol,
+                            maxiter=20000, assembled_rhs=True)
+    elif world > 1:
+      from swirl_fem_amd.linalg.cg import cg as cg_solve
+      xv, vinfo = cg_solve(A, A(xs).clone(), tol=vtol, maxiter=20000,
+                           M=mesh.exchange, reduce_fn=part.reduce_sum_)
+    else:
+      from swirl_fem_amd.linalg.cg import cg as cg_solve
+      xv, vinfo = cg_solve(A, A(xs).clone(), tol=vtol, maxiter=20000)
+    err = torch.stack([(xv - xs).abs().max(), xs.abs().max()]).double()
+    if world > 1:
+      err = comm.all_reduce_max_(err)
+    verify = {'rel_err_vs_manufactured': float(err[0] / err[1]),
+              'iterations': int(vinfo['num_iterations']),
+              'status': str(vinfo.get('status')), 'tol': vtol}
+
   if rank == 0:
     res = {
         'metric': 'GDOF/s per CG iteration, 3D p=%d %s' % (
@@ -521,9 +593,12 @@ def main():
                 '' if args.no_overlap or args.partitioned != 'consistent'
                 else ', exchange overlapped with interior elements'))
             if world > 1 else None,
-            'backend': ('rccl' if args.backend == 'nccl' else 'gloo '
-                        '(rehearsal)') if world > 1 else None,
-            'world_size_seen': dist.get_world_size() if world > 1 else 1,
+            'backend': {'nccl': 'rccl', 'gloo': 'gloo (rehearsal)',
+                        'threads': 'threads of one process on one GPU '
+                                   '(rehearsal)'}[args.backend]
+            if world > 1 else None,
+            'world_size_seen': comm.get_world_size() if world > 1 else 1,
+            'verify': verify,
             'per_rank': per_rank,
             'strong_ref': strong_ref,
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
@@ -596,9 +671,7 @@ def main():
       res['cpu_baseline'] = cpu_baseline(P, ne=min(32, args.n) if args.p <= 7 else min(12, args.n))
     else:
       res['cpu_baseline'] = None
-    print(json.dumps(res))
-  if world > 1:
-    dist.destroy_process_group()
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':

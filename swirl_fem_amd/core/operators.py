@@ -203,7 +203,11 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
       # multilinear 0.92 -> 0.87, stored 1.86 -> 1.80 at config 2; elements
       # that span several waves (P >= 9) lose with them (p = 11 fp32 box 1.74
       # vs 1.46 ms)
-      if seg_len > 1 and (P <= 8 or os.environ.get('SFEM_CHAIN_HI') == '1'):
+      # (P >= 9 has chain instantiations for box / affine elements only:
+      # FacetElem::CHAINS; the library refuses the others)
+      if seg_len > 1 and (P <= 8 or (
+          os.environ.get('SFEM_CHAIN_HI') == '1' and
+          mode in (_GEO_BOX, _GEO_AFFINE))):
         new['chains'] = facet_chains(mesh.elements, ids, P, seg_len)
         new['chain_len'] = seg_len
     out.append(new)

@@ -967,8 +967,8 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
 
 // ----------------------------------------------------------------- launch ---
 template <typename T, int P, typename ELEM>
-void launch_facet_elem(const FacetParams<T>& prm, const typename ELEM::Mat& mat,
-                       unsigned groups, bool off32, hipStream_t stream) {
+int launch_facet_elem(const FacetParams<T>& prm, const typename ELEM::Mat& mat,
+                      unsigned groups, bool off32, hipStream_t stream) {
   const dim3 grid(groups), block(FacetLayout<P>::BLOCK);
   if (prm.chain_off) {
     if constexpr (ELEM::CHAINS) {
@@ -979,8 +979,10 @@ void launch_facet_elem(const FacetParams<T>& prm, const typename ELEM::Mat& mat,
         hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, false>), grid,
                            block, 0, stream, prm, mat);
     } else {
+      // (nothing was launched: the caller must not read `out`)
       set_error("helmholtz (facet): no chain kernel for this geometry at P=%d",
                 P);
+      return SFEM_EUNSUPPORTED;
     }
   } else if (prm.ncomp == 1) {
     if (off32)
@@ -997,6 +999,7 @@ void launch_facet_elem(const FacetParams<T>& prm, const typename ELEM::Mat& mat,
       hipLaunchKernelGGL((helmholtz_facet_kernel<T, P, ELEM, false, false>),
                          grid, block, 0, stream, prm, mat);
   }
+  return SFEM_OK;
 }
 
 // `groups`: workgroups of the launch = elements, or chain segments when
@@ -1022,26 +1025,28 @@ int launch_helmholtz_facet(const FacetParams<T>& prm, int geo_mode,
   const char* force64 = getenv("SFEM_FACET_OFF64");
   const bool off32 = (uint64_t)field_reals * sizeof(T) < ((uint64_t)1 << 32) &&
                      !(force64 && force64[0] == '1');
+  int rc = SFEM_OK;
   if (geo_mode == GEO_BOX) {
     const SMat<T, P> sm = make_smat<T, P>(dmat, weights);
-    if (mass) launch_facet_elem<T, P, BoxElem<T, P, true>>(prm, sm, g, off32,
-                                                           stream);
-    else launch_facet_elem<T, P, BoxElem<T, P, false>>(prm, sm, g, off32,
-                                                       stream);
+    if (mass) rc = launch_facet_elem<T, P, BoxElem<T, P, true>>(prm, sm, g,
+                                                                off32, stream);
+    else rc = launch_facet_elem<T, P, BoxElem<T, P, false>>(prm, sm, g, off32,
+                                                            stream);
   } else {
     const DMat<T, P> dm = make_dmat<T, P>(dmat, weights, nodes);
 #define SFEM_FACET_GM(GMV)                                                    \
   do {                                                                        \
-    if (mass) launch_facet_elem<T, P, FacetElem<T, P, GMV, true>>(            \
-        prm, dm, g, off32, stream);                                    \
-    else launch_facet_elem<T, P, FacetElem<T, P, GMV, false>>(                \
-        prm, dm, g, off32, stream);                                    \
+    if (mass) rc = launch_facet_elem<T, P, FacetElem<T, P, GMV, true>>(       \
+        prm, dm, g, off32, stream);                                           \
+    else rc = launch_facet_elem<T, P, FacetElem<T, P, GMV, false>>(           \
+        prm, dm, g, off32, stream);                                           \
   } while (0)
     if (geo_mode == GEO_AFFINE) SFEM_FACET_GM(GEO_AFFINE);
     else if (geo_mode == GEO_MULTILINEAR) SFEM_FACET_GM(GEO_MULTILINEAR);
     else SFEM_FACET_GM(GEO_POINT);
 #undef SFEM_FACET_GM
   }
+  if (rc != SFEM_OK) return rc;
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

@@ -55,7 +55,7 @@ def _setup_group():
   """A gloo process group over all ranks for setup-time collectives (created
   once; every rank must reach this call)."""
   dist = comm.dist
-  if dist.get_backend() == 'gloo':
+  if comm.transport() is not None or dist.get_backend() == 'gloo':
     return None
   if 'group' not in _SETUP_GROUP:
     _SETUP_GROUP['group'] = dist.new_group(backend='gloo')

@@ -30,17 +30,63 @@ import torch.distributed as dist
 # the split exchange then goes through it instead of posting P2P operations.
 _BLOCKING_TRANSPORT = False
 
+# None: ranks are processes and talk through `torch.distributed` (RCCL / gloo).
+# An `inprocess.ThreadWorld`: ranks are threads of this process that share one
+# GPU (`bench.py --backend threads`: the 2 x 2 x 2 layout of `--gpus 8` on a
+# one-GPU box, whose process limit rules out eight gloo ranks).
+_TRANSPORT = None
+
+
+def set_transport(world) -> None:
+  global _TRANSPORT
+  _TRANSPORT = world
+
+
+def transport():
+  return _TRANSPORT
+
 
 def get_rank() -> int:
+  if _TRANSPORT is not None:
+    return _TRANSPORT.rank
   if dist.is_available() and dist.is_initialized():
     return dist.get_rank()
   return int(os.environ.get('RANK', '0'))
 
 
 def get_world_size() -> int:
+  if _TRANSPORT is not None:
+    return _TRANSPORT.world
   if dist.is_available() and dist.is_initialized():
     return dist.get_world_size()
   return int(os.environ.get('WORLD_SIZE', '1'))
+
+
+def barrier() -> None:
+  """All ranks (no-op for a single rank)."""
+  if _TRANSPORT is not None:
+    _TRANSPORT.barrier.wait()
+  elif dist.is_available() and dist.is_initialized() and get_world_size() > 1:
+    dist.barrier()
+
+
+def all_reduce_max_(t: torch.Tensor) -> torch.Tensor:
+  if _TRANSPORT is not None:
+    return _TRANSPORT.all_reduce(t, torch.maximum)
+  if dist.is_available() and dist.is_initialized() and get_world_size() > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return t
+
+
+def all_gather(t: torch.Tensor) -> list:
+  """[rank 0's t, rank 1's t, ...] on every rank."""
+  if _TRANSPORT is not None:
+    return _TRANSPORT.all_gather(t)
+  if dist.is_available() and dist.is_initialized() and get_world_size() > 1:
+    every = [torch.zeros_like(t) for _ in range(get_world_size())]
+    dist.all_gather(every, t)
+    return every
+  return [t]
 
 
 @dataclasses.dataclass(eq=False)
@@ -165,6 +211,8 @@ def exchange_buffers(plan: NeighborPlan, send_bufs, group=None,
   One grouped batch of P2P ops (RCCL: ncclGroupStart ... ncclGroupEnd), so all
   neighbour links are driven concurrently.
   """
+  if _TRANSPORT is not None:
+    return _TRANSPORT.exchange(plan, send_bufs, recv_bufs)
   if recv_bufs is None:
     recv_bufs = [torch.empty_like(b) for b in send_bufs]
   if not plan.neighbors:
@@ -233,8 +281,8 @@ def neighbor_exchange_start(u: torch.Tensor, plan: NeighborPlan, group=None):
   send = _ops.pack_strided(u, cat)
   recv = torch.empty_like(send)
   sends, recvs = list(torch.split(send, sizes)), list(torch.split(recv, sizes))
-  if _BLOCKING_TRANSPORT or (send.is_cuda and
-                             dist.get_backend(group) == 'gloo'):
+  if _BLOCKING_TRANSPORT or _TRANSPORT is not None or (
+      send.is_cuda and dist.get_backend(group) == 'gloo'):
     exchange_buffers(plan, sends, group=group, recv_bufs=recvs)   # blocking
     return (recv, cat, [], send, plan)
   ops = []
@@ -259,6 +307,8 @@ def neighbor_exchange_finish(handle, u: torch.Tensor) -> torch.Tensor:
 
 def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
   """In-place sum over ranks (the CG scalars; one fused all-reduce)."""
+  if _TRANSPORT is not None:
+    return _TRANSPORT.all_reduce(t, torch.add)
   if dist.is_available() and dist.is_initialized() and get_world_size() > 1:
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
   return t

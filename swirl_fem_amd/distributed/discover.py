@@ -31,6 +31,9 @@ def discover_neighbors(global_keys, group=None, device='cpu') -> NeighborPlan:
   a key may occur once per rank (images of one DOF on the same rank are the
   local periodic exchange's business and are skipped here).
   `device`: where the routing buffers live ('cpu' for gloo, a GPU for RCCL)."""
+  from swirl_fem_amd.distributed import comm
+  if comm.transport() is not None:      # ranks are threads of this process
+    return comm.transport().discover(global_keys)
   rank, world = dist.get_rank(group), dist.get_world_size(group)
   keys = torch.as_tensor(np.asarray(global_keys), dtype=torch.int64,
                          device=device)

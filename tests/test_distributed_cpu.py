@@ -393,3 +393,116 @@ def test_bench_two_ranks_on_the_gpu_as_a_plain_command():
   assert line['config']['world_size_seen'] == 2
   assert len(line['config']['per_rank']['apply_ms']) == 2
   assert line['roofline']['frac'] <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('flags,blocks', [
+    (('--elems', '16'), '2x2x2'),
+    (('--elems', '16', '--periodic'), '2x2x2'),
+    (('--scaling', 'strong', '--elems', '32'), '2x2x2')])
+def test_bench_eight_ranks_with_real_kernels_on_one_gpu(flags, blocks):
+  """The whole `--gpus 8` bench path with real kernels, on the one GPU of the
+  box: 2 x 2 x 2 rank-local blocks (7 neighbours per rank, nodes held by 4 and
+  8 ranks), `OverlappedHelmholtz`, the consistent CG with its two scalar
+  all-reduces, the per-rank gather and the JSON line -- as eight THREADS of
+  one process (`--backend threads`, `distributed/inprocess.py`), because the
+  box allows six processes on its card.  `--verify` solves A x = A x* for a
+  manufactured x* through the timed operator and solver on all ranks.
+  Reference: core/premesh.py:170-222, core/gather_scatter.py:318-358."""
+  res, line = _run_bench('--gpus', '8', '--backend', 'threads', *flags,
+                         '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                         '--no-general', '--verify', timeout=900)
+  assert res.returncode == 0, res.stderr[-3000:]
+  assert sum(l.startswith('{') for l in res.stdout.splitlines()) == 1
+  cfg = line['config']
+  assert line['n_gpus'] == 8 and cfg['world_size_seen'] == 8
+  assert cfg['blocks'] == blocks
+  assert line['value'] is not None and line['value'] > 0
+  for key in ('apply_ms', 'exchange_ms', 'interface_values'):
+    assert len(cfg['per_rank'][key]) == 8, key
+  assert min(cfg['per_rank']['interface_values']) > 0
+  assert cfg['verify']['status'] == 'converged', cfg['verify']
+  assert cfg['verify']['rel_err_vs_manufactured'] < 1e-8, cfg['verify']
+  if '--periodic' in flags:
+    assert cfg['periodic_dims'] == [0, 1, 2]
+    assert cfg['dofs_global'] == (2 * 16 * 7) ** 3
+  elif '--scaling' in flags:
+    assert cfg['dofs_global'] == (32 * 7 + 1) ** 3 and line['scaling'] == 'strong'
+  else:
+    assert cfg['dofs_global'] == (2 * 16 * 7 + 1) ** 3
+
+
+@pytest.mark.gpu
+def test_bench_four_gloo_ranks_verify_on_the_gpu():
+  """Four PROCESS ranks (2 x 2 x 1 blocks) sharing the GPU over gloo, the
+  launch path of the driver's scaling run, with the manufactured-solution
+  check on the result."""
+  res, line = _run_bench('--gpus', '4', '--backend', 'gloo', '--elems', '8',
+                         '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                         '--no-general', '--verify', timeout=900)
+  assert res.returncode == 0, res.stderr[-3000:]
+  cfg = line['config']
+  assert line['n_gpus'] == 4 and cfg['world_size_seen'] == 4
+  assert cfg['blocks'] == '2x2x1' and len(cfg['per_rank']['apply_ms']) == 4
+  assert cfg['verify']['status'] == 'converged', cfg['verify']
+  assert cfg['verify']['rel_err_vs_manufactured'] < 1e-8, cfg['verify']
+
+
+@pytest.mark.parametrize('periodic', [(), (0, 1, 2)])
+def test_thread_world_transport(periodic):
+  """`distributed/inprocess.py`: eight threads as the ranks of the 2 x 2 x 2
+  grid.  Block plans (on the periodic box: through the transport's neighbour
+  discovery) are symmetric pair by pair, an exchange of ones counts every
+  global node once, reductions and gathers agree on all ranks."""
+  import torch
+  from swirl_fem_amd.distributed import blocks, comm, inprocess
+  grid, n, P = (2, 2, 2), 2, 3
+  world = inprocess.ThreadWorld(8)
+
+  def rank_main(rank):
+    assert comm.get_rank() == rank and comm.get_world_size() == 8
+    part = blocks.build_block_partition(n, P, grid, rank, device='cpu',
+                                        periodic_dims=periodic)
+    ones = torch.ones(part.mesh.num_nodes, dtype=torch.float64)
+    idx = [torch.as_tensor(ix, dtype=torch.int64) for ix in part.plan.indices]
+    recv = comm.exchange_buffers(part.plan, [ones[ix] * (rank + 1)
+                                             for ix in idx])
+    holders = ones.clone()
+    for q, rb, ix in zip(part.plan.neighbors, recv, idx):
+      assert bool((rb == q + 1).all())
+      holders.index_add_(0, ix, torch.ones_like(rb))
+    total = comm.all_reduce_sum_(torch.tensor([float((1 / holders).sum())],
+                                              dtype=torch.float64))
+    top = comm.all_reduce_max_(torch.tensor([float(rank)]))
+    every = comm.all_gather(torch.tensor([rank]))
+    comm.barrier()
+    return part, float(total), float(top), [int(t) for t in every]
+
+  res = world.run(rank_main)
+  assert comm.transport() is None
+  parts = [res[r][0] for r in range(8)]
+  for r in range(8):
+    assert abs(res[r][1] - parts[0].num_global_nodes) < 1e-9
+    assert res[r][2] == 7.0 and res[r][3] == list(range(8))
+    assert len(parts[r].plan.neighbors) == 7
+    for q, ix in zip(parts[r].plan.neighbors, parts[r].plan.indices):
+      j = parts[q].plan.neighbors.index(r)
+      assert np.array_equal(parts[r].global_keys[ix] if not periodic else
+                            np.sort(parts[r].global_keys[ix]),
+                            parts[q].global_keys[parts[q].plan.indices[j]]
+                            if not periodic else
+                            np.sort(parts[q].global_keys[parts[q].plan.indices[j]]))
+
+
+def test_thread_world_reports_the_failing_rank():
+  from swirl_fem_amd.distributed import comm, inprocess
+  world = inprocess.ThreadWorld(3)
+
+  def rank_main(rank):
+    if rank == 1:
+      raise ValueError('boom on rank one')
+    comm.barrier()
+
+  with pytest.raises(RuntimeError, match='rank 1 failed(.|\n)*boom'):
+    world.run(rank_main)
+  assert comm.transport() is None

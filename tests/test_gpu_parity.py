@@ -16,6 +16,7 @@ from swirl_fem_amd.core.fespace import FiniteElementSpace, div, grad
 from swirl_fem_amd.core.interpolation import (Nodes1D, NodeType, Quadrature1D)
 from swirl_fem_amd.core.mesh import Mesh
 from swirl_fem_amd.core.mesh_refiner import refine_premesh
+from tests.fp32util import F32Rng, f32_mesh
 from swirl_fem_amd.core.premesh import Premesh
 
 pytestmark = pytest.mark.gpu
@@ -51,6 +52,8 @@ def make_case(ndim, n, P, jitter=0.1, seed=0, periodic=(), scramble=False):
 
 
 def spaces(rp, P, q, qt, dtype=torch.float64):
+  # (fp32: node coordinates the kernels can hold, tests/fp32util.py)
+  rp = f32_mesh(rp, dtype)
   mesh = rp.finalize(device=DEV, dtype=dtype)
   quad = Quadrature1D.create(q, NT[qt])
   fes = FiniteElementSpace.create(mesh, quad)
@@ -486,11 +489,11 @@ def test_fused_helmholtz_on_gmsh_meshes(name, ndim, P):
                                       (3, 1, 12)])
 def test_fused_helmholtz_fp32_and_vector(ndim, n, P):
   rp = make_case(ndim, n, P, seed=13)
-  rng = np.random.default_rng(14)
+  rng = F32Rng(14)
   for dtype in (torch.float32, torch.float64):
     mesh, fes, ofes = spaces(rp, P, P, 'gll', dtype)
     bmask = mesh.physical_masks['boundary'].cpu().numpy()
-    tol = 1e-10 if dtype == torch.float64 else 3e-5
+    tol = TOL[dtype]
     for geometry in ('auto', 'stored'):
       op = fes.helmholtz_operator(mesh.physical_masks['boundary'], geometry)
       for nc in (1, 2, 3):
@@ -523,7 +526,7 @@ def test_matrix_core_helmholtz_p11_fp32(mode, monkeypatch):
   curved elements keeps those on the vector-ALU kernel)."""
   from swirl_fem_amd import _lib
   P, n = 12, 2 if mode != 'mixed' else 3
-  rng = np.random.default_rng(71)
+  rng = F32Rng(71)
   pm = unit_cube_mesh(n, ndim=3)
   x = pm.node_coords.copy()
   if mode == 'sheared':
@@ -558,13 +561,13 @@ def test_matrix_core_helmholtz_p11_fp32(mode, monkeypatch):
     monkeypatch.setenv('SFEM_MFMA', '1')
     parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64, device=DEV)
     got = op.apply(ud, l0, l1, dot_out=parts)
-    assert relerr(got, ref) < 2e-5, (mode, l0, l1)
+    assert relerr(got, ref) < 1e-5, (mode, l0, l1)
     want, scale = float((u * ref).sum()), float(np.abs(u * ref).sum())
     assert abs(float(parts.sum()) - want) <= 3e-4 * scale
     monkeypatch.setenv('SFEM_MFMA', '0')
     assert 'helmholtz_kernel<float, 12' in op.kernel_name(l0, l1)
     valu = op.apply(ud, l0, l1)
-    assert relerr(valu, ref) < 2e-5
+    assert relerr(valu, ref) < 1e-5
     assert relerr(got, valu.cpu().numpy()) < 1e-5
 
 
@@ -573,8 +576,8 @@ def test_matrix_core_helmholtz_p11_fp32(mode, monkeypatch):
 def test_fused_helmholtz_geometry_kinds(ndim, n, P, dtype):
   """Affine / multilinear elements evaluate their factors in registers,
   curved elements read stored factors; a mesh may mix all three."""
-  rng = np.random.default_rng(19)
-  tol = 1e-10 if dtype == torch.float64 else 3e-5
+  rng = F32Rng(19)
+  tol = TOL[dtype]
   for mode in ('structured', 'sheared', 'vertex', 'curved', 'mixed'):
     pm = unit_cube_mesh(n, ndim=ndim)
     x = pm.node_coords.copy()
@@ -616,9 +619,11 @@ def test_fused_helmholtz_geometry_kinds(ndim, n, P, dtype):
       for g, o in ops.items():
         assert relerr(o.apply(dev(uu, dtype), 0.4, 1.1), ref) < tol, (mode, g)
     # pure stiffness through the ASSEMBLED kernels: lambda0 = 0 selects the
-    # MASS=false instantiations (for structured / sheared 3D P = 8 fp64 that is
-    # helmholtz_kernel<double,8,3,true,true,1,true,false>, the kernel bench.py
-    # times), with and without the fused u . A u, scalar and component-major
+    # MASS=false instantiations, with and without the fused u . A u, scalar
+    # and component-major.  (n = 3 runs unchained here; the instantiation
+    # bench.py times is pinned at its chain length by tests/test_gpu_facet.py::
+    # test_headline_chain_instantiation_matches_oracle and, at full size, by
+    # test_config2_properties_full_size[0.0-64].)
     from swirl_fem_amd import _lib
     for nc in (1, ndim):
       u = rng.standard_normal((mesh.num_nodes, nc))
@@ -657,10 +662,10 @@ def test_fused_helmholtz_cluster_assembly(n, P, scramble, dtype):
   from swirl_fem_amd import _lib
   from swirl_fem_amd.core import operators
   rp = make_case(3, n, P, seed=41 + P, scramble=scramble)
-  rng = np.random.default_rng(43)
+  rng = F32Rng(43)
   mesh, fes, ofes = spaces(rp, P, P, 'gll', dtype)
   bmask = mesh.physical_masks['boundary'].cpu().numpy()
-  tol = 1e-10 if dtype == torch.float64 else 3e-5
+  tol = TOL[dtype]
   for geometry in ('auto', 'stored'):
     ops = {a: operators.HelmholtzOperator.create(
         fes, mesh.physical_masks['boundary'], geometry, a)
@@ -1294,19 +1299,37 @@ def test_poisson_reference_1d_and_circle():
 
 # -------------------------------------------- full-size properties (config 2)
 @pytest.mark.parametrize('n', [int(os.environ.get('SFEM_TEST_FULL_N', '64'))])
-def test_config2_properties_full_size(n):
+@pytest.mark.parametrize('jitter', [0.2, 0.0])
+def test_config2_properties_full_size(n, jitter):
   """3D p=7 Laplacian at bench scale: symmetry, nullspace, linearity,
-  fused == generic path, assembled == deterministic assembly."""
+  fused == generic path, assembled == deterministic assembly == stored
+  factors.  `jitter = 0.2`: deformed mesh, multilinear chain kernel;
+  `jitter = 0`: the Cartesian mesh bench.py times, i.e. the box chain kernel
+  `helmholtz_chain_kernel<double, 8, BoxElem<double, 8, false>>` on segments
+  of 8 (asserted by name and by the chain list)."""
   P = 8
   rng = np.random.default_rng(18)
   pm = unit_cube_mesh(n, ndim=3)
   h = 1.0 / n
-  pm = pm.replace(node_coords=pm.node_coords + 0.2 * h *
-                  rng.uniform(-1, 1, pm.node_coords.shape))
+  if jitter:
+    pm = pm.replace(node_coords=pm.node_coords + jitter * h *
+                    rng.uniform(-1, 1, pm.node_coords.shape))
   grid = Nodes1D.create(P, NT['gll'])
   mesh = refine_premesh(pm, grid).finalize(device=DEV)
   fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
   op = fes.helmholtz_operator(None)
+  from swirl_fem_amd.core import operators
+  assert len(op.facet_parts) == 1
+  elem = ('sfem::FacetElem<double, 8, 3, false>' if jitter
+          else 'sfem::BoxElem<double, 8, false>')
+  if operators.chain_segment_length(mesh.num_elements) > 1:
+    assert op.kernel_name(0.0, 1.0) == (
+        'sfem::helmholtz_chain_kernel<double, 8, %s, ' % elem)
+    off = op.facet_parts[0]['chains'][0]
+    seg = operators.chain_segment_length(mesh.num_elements)
+    assert int((off[1:] - off[:-1]).max()) == min(seg, n)
+    if n >= 64:
+      assert seg == 8 and bool(((off[1:] - off[:-1]) == 8).all())
   g = torch.Generator(device=DEV).manual_seed(0)
   u = torch.randn(mesh.num_nodes, dtype=torch.float64, device=DEV, generator=g)
   v = torch.randn(mesh.num_nodes, dtype=torch.float64, device=DEV, generator=g)
@@ -1345,6 +1368,16 @@ def test_config2_properties_full_size(n):
   # A x = A x* on the Dirichlet problem and watch |x - x*|_A
   bm = mesh.physical_masks['boundary']
   op_d = fes.helmholtz_operator(bm)
+  assert op_d.kernel_name(0.0, 1.0) == op.kernel_name(0.0, 1.0)
+  # ... with the Dirichlet rows: chain kernel == index-row kernel
+  os.environ['SFEM_FACET'] = '0'
+  try:
+    op_rows = operators.HelmholtzOperator.create(fes, bm)   # (not the cached)
+  finally:
+    del os.environ['SFEM_FACET']
+  assert op_rows.facet_parts is None
+  assert float((op_rows.apply(u) - op_d.apply(u)).abs().max()) < 1e-11 * scale
+  del op_rows
   xs = u * (~bm)
   from swirl_fem_amd.linalg.cg import CGRunner
   run = CGRunner(op_d.linear_operator(0.0, 1.0), op_d.apply(xs), tol=0.0,
