@@ -265,6 +265,11 @@ def main():
                   help='smooth mesh deformation amplitude (fraction of h)')
   ap.add_argument('--graph', action='store_true',
                   help='N=1: replay each CG iteration as one HIP graph launch')
+  ap.add_argument('--repeats', type=int, default=4,
+                  help='further timed batches of --steps iterations after the '
+                       'one `value` is computed from; their ms per step go to '
+                       'config.repeat_ms_per_step (box-to-box and run-to-run '
+                       'spread of a 30 ms measurement)')
   ap.add_argument('--dry-run', action='store_true',
                   help='rehearse launch, rendezvous, block build and one '
                        'interface exchange on CPU tensors (gloo) and print a '
@@ -363,6 +368,7 @@ def rank_main(args, world, rank, device):
   import torch
   from swirl_fem_amd.core.fespace import FiniteElementSpace
   from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
+  from swirl_fem_amd import switches
   from swirl_fem_amd.distributed import comm
   from swirl_fem_amd.linalg.cg import CGRunner
 
@@ -449,6 +455,18 @@ def rank_main(args, world, rank, device):
     elapsed = float(comm.all_reduce_max_(tt).item())
   ms_per_step = 1e3 * elapsed / args.steps
   value = N_global / (elapsed / args.steps) / 1e9
+  repeat_ms = []
+  for _ in range(max(0, args.repeats)):
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+      run.step()
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64,
+                      device=device)
+    if world > 1:
+      tt = comm.all_reduce_max_(tt)
+    repeat_ms.append(1e3 * float(tt.item()) / args.steps)
 
   # ---- roofline of the dominant kernel: HIP events around ONE apply as the
   # solver issues it -- the fused kernel and whatever it needs around it (the
@@ -470,16 +488,30 @@ def rank_main(args, world, rank, device):
     torch.cuda.synchronize()
     return float(np.mean([x.elapsed_time(y) for x, y in pairs]))
 
-  kern_ms = time_apply(op)
+  # what the solver issues: with layered assembly (`CGRunner.layered`) the
+  # apply stores into an extended vector, nothing is cleared, no atomics
+  layered = getattr(run, 'layered', None)
+  if layered is not None:
+    class _LayeredApply:       # same call shape as `HelmholtzOperator.apply`
+      def __init__(self, operator):
+        self.op, self.ext = operator, operator.new_extended()
+      def apply(self, v, l0, l1, out=None):
+        return self.op.apply_layered(v, self.ext, l0, l1)
+    solver_apply = _LayeredApply(op)
+  else:
+    solver_apply = op
+  kern_ms = time_apply(solver_apply)
   # back-to-back applies (no event between them)
   s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
       enable_timing=True)
   s0.record()
   for _ in range(args.steps):
-    op.apply(u, args.mass_coeff, 1.0, out=out_buf)
+    solver_apply.apply(u, args.mass_coeff, 1.0, out=out_buf)
   s1.record()
   torch.cuda.synchronize()
   apply_ms = s0.elapsed_time(s1) / args.steps
+  if layered is not None:
+    del solver_apply
   per_rank = None
   if world > 1:
     # per-rank figures: local apply (above) and the interface exchange alone
@@ -528,7 +560,10 @@ def rank_main(args, world, rank, device):
   ngeo = 7 if args.mass_coeff else 6
   model_bytes = algorithmic_bytes_per_apply(E, n, N_local, sizeof=sizeof,
                                             ngeo=ngeo)
-  kernel_bytes = op.bytes_per_apply(args.mass_coeff)
+  kernel_bytes = op.bytes_per_apply(args.mass_coeff,
+                                    layered=layered is not None)
+  layer_reads = (0 if layered is None
+                 else sizeof * sum(ln for ln, _ in layered.layers))
   achieved = kernel_bytes / (kern_ms * 1e-3) / 1e9
   traffic, traffic_sha = measured_traffic(args.n, args.p, args.dtype,
                                           args.geometry, args.jitter)
@@ -603,6 +638,16 @@ def rank_main(args, world, rank, device):
             'strong_ref': strong_ref,
             'apply_only_gdofs': N_local * world / (apply_ms * 1e-3) / 1e9,
             'apply_ms': apply_ms, 'setup_s': setup_s,
+            'repeat_ms_per_step': repeat_ms,
+            'median_ms_per_step': float(np.median([ms_per_step] + repeat_ms)),
+            'assembly': (
+                'atomic (shared nodes: global_atomic_add after clearing their '
+                'range)' if layered is None else
+                'layered: %d layers behind the nodal vector, %d of %d values '
+                'per apply stored to a further layer, no atomics, nothing '
+                'cleared; r -= alpha Ap adds the layers up' % (
+                    len(layered.layers), layered.written - N_local, N_local)),
+            'switches': switches.active(),
             'geometry': ('%s: %d affine + %d multilinear elements (factors '
                          'evaluated in registers), %d with 6 stored factors '
                          'per point' % (args.geometry, op.num_affine,
@@ -620,13 +665,18 @@ def rank_main(args, world, rank, device):
                               'workload was not profiled or the kernel sources '
                               '(sha256 in traffic_profiled_at) have changed '
                               'since' % TRAFFIC_FILE,
-            'kernel': op.kernel_name(args.mass_coeff, 1.0),
+            'kernel': op.kernel_name(args.mass_coeff, 1.0,
+                                     layered=layered is not None),
             'kernel_ms': kern_ms,
             'kernel_ms_covers': 'one apply as the solver issues it: the fused '
                                 'kernel plus the clearing of the atomically '
-                                'accumulated node range it needs, if any',
+                                'accumulated node range it needs, if any '
+                                '(layered assembly: none)',
             'bytes_per_launch': kernel_bytes,
-            'bytes_model': 'u s N + out s N + connectivity (432 B per element '
+            'bytes_model': ('layered assembly: out is s x (N + values stored '
+                            'to further layers) instead of s N; ' if layered
+                            is not None else '') +
+                           'u s N + out s N + connectivity (432 B per element '
                            'from a facet table, + 4 B on a chain list; 4 n + '
                            '2 S per element on index rows) + geometry (64 B '
                            'per affine / box element, 24 reals per multilinear '
@@ -643,7 +693,7 @@ def rank_main(args, world, rank, device):
             'model_bytes_per_launch': model_bytes,
         },
     }
-    cg_bytes = kernel_bytes + passes * sizeof * N_local
+    cg_bytes = kernel_bytes + passes * sizeof * N_local + layer_reads
     res['roofline_cg_iteration'] = {
         'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
         'achieved': cg_bytes / (ms_per_step * 1e-3) / 1e9,

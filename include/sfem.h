@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFEM_ABI_VERSION 4
+#define SFEM_ABI_VERSION 5
 
 enum { SFEM_F32 = 0, SFEM_F64 = 1 };
 enum {
@@ -302,6 +302,17 @@ typedef struct sfem_helmholtz_args {
   const int32_t* chain_offsets;   /* (num_chains + 1,)                        */
   const int32_t* chain_elems;     /* (chain_offsets[num_chains],)             */
   int64_t num_chains;
+  /* apply with facet_table, scalar fields: layered assembly (0 = off).  `out` */
+  /* is then an extended vector of layered_extent reals (see                   */
+  /* sfem_cg_update_r_layered) and facet_table is in its LAYERED form          */
+  /*   { id0 | flags,  position in `out` | SFEM_IDX_DIRICHLET,  sa,            */
+  /*     (si & 0xffff) | (sj << 16) }                                          */
+  /* where the position is layer base + id0 of the layer this (element, facet) */
+  /* writes: every writer of a facet has a layer of its own (in a chain        */
+  /* segment the element that hands a face on does not write it, its successor */
+  /* writes the sum).  Slots no element writes must hold zero; the kernel      */
+  /* issues plain stores only and clears nothing (zero_begin/zero_end unused). */
+  int64_t layered_extent;
 } sfem_helmholtz_args;
 
 /* Compact connectivity of refiner-numbered meshes (reference numbering:
@@ -545,6 +556,27 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
                      int fuse_rr, int dtype, sfem_stream_t stream);
 int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
                       double* scalars, int dtype, sfem_stream_t stream);
+/* Layered assembly (sfem_helmholtz_args.layered_extent): the operator result
+ * is an EXTENDED vector  [ count nodal values | layer 1 | layer 2 | ... ];
+ * layer k (k = 0 .. num_layers-1 here) holds further contributions to the
+ * nodes [0, layer_len[k]) and starts at element layer_off[k] of the vector
+ * (HOST arrays; lengths and offsets multiples of 16 bytes, lengths not
+ * increasing, at most SFEM_MAX_LAYERS).  The assembled value of node i is
+ *   ext[i] + sum_{k : i < layer_len[k]} ext[layer_off[k] + i],
+ * added in layer order -- the direct-stiffness sum of core/gather_scatter.py:
+ * 130-133 in a fixed order: no atomics, no cleared range, bitwise reproducible.
+ * sfem_cg_update_r_layered = sfem_cg_update_r (cg.py:81) reading Ap that way,
+ * where it streams Ap anyway; sfem_fold_layers writes the assembled values
+ * back into ext[0 .. count) for every other consumer.                         */
+#define SFEM_MAX_LAYERS 15
+int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
+                             const int64_t* layer_len,
+                             const int64_t* layer_off, int num_layers,
+                             double* scalars, int fuse_rr, int dtype,
+                             sfem_stream_t stream);
+int sfem_fold_layers(void* out_ext, int64_t count, const int64_t* layer_len,
+                     const int64_t* layer_off, int num_layers, int dtype,
+                     sfem_stream_t stream);
 int sfem_cg_update_r_mean(void* r, const void* ap, const void* w,
                           int64_t count, double* scalars, double* sums,
                           int dtype, sfem_stream_t stream);

@@ -41,12 +41,14 @@ def random_orientations(pm, rng):
 
 
 def make_mesh(ndim, n, P, mode, rng):
-  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.common.premesh_commons import box_mesh, unit_cube_mesh
   from swirl_fem_amd.core.interpolation import Nodes1D, NodeType
   from swirl_fem_amd.core.mesh_refiner import refine_premesh
   pm = unit_cube_mesh(n, ndim=ndim)
+  if mode == 'sheared 8x2x2':      # elements of aspect ratio 4, then sheared
+    pm = box_mesh((8, 2, 2), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
   x = pm.node_coords.copy()
-  if mode == 'sheared':
+  if mode in ('sheared', 'sheared 8x2x2'):
     x = x @ (np.eye(ndim) + 0.3 * rng.uniform(-1, 1, (ndim, ndim))).T + 0.1
   elif mode in ('jittered', 'curved'):
     x = x + 0.1 / n * rng.uniform(-1, 1, x.shape)
@@ -74,8 +76,9 @@ def helmholtz_rows(out):
            (2, 4, 4), (2, 3, 6), (2, 3, 8), (2, 3, 12)]
   forms = {'mass': (1.0, 0.0), 'stiffness': (0.0, 1.0),
            'helmholtz': (0.6, 1.4)}
-  for (ndim, n, P), mode in itertools.product(
-      cases, ('structured', 'sheared', 'jittered', 'curved')):
+  for (ndim, n, P), mode in list(itertools.product(
+      cases, ('structured', 'sheared', 'jittered', 'curved'))) + [
+          ((3, 2, 8), 'sheared 8x2x2')]:
     rng = np.random.default_rng(1000 * ndim + 10 * P + len(mode))
     rp = make_mesh(ndim, n, P, mode, rng)
     mesh = rp.finalize(device=dev, dtype=torch.float32)

@@ -10,10 +10,12 @@ from __future__ import annotations
 import ctypes
 import os
 
+from swirl_fem_amd import switches
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SFEM_LIB: another build of the same library (kernel A/B experiments)
-LIB_PATH = os.environ.get('SFEM_LIB') or os.path.join(_HERE, 'libsfem_hip.so')
-ABI_VERSION = 4
+LIB_PATH = switches.get('SFEM_LIB') or os.path.join(_HERE, 'libsfem_hip.so')
+ABI_VERSION = 5
 
 SFEM_F32, SFEM_F64 = 0, 1
 SFEM_CG_NSCALARS_NAMED = 16
@@ -22,6 +24,7 @@ CG_STATUS = {0: 'running', 1: 'converged', 2: 'maxiter', 3: 'breakdown_pAp',
              4: 'breakdown_gamma'}
 SFEM_DOT_SLOTS = 1024
 SFEM_CG_MEAN_SUMS = 256    # 2 parities x (64 sums of 1.r + 64 sums of w.r)
+SFEM_MAX_LAYERS = 15
 
 c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_void_p)
@@ -43,6 +46,7 @@ class HelmholtzArgs(ctypes.Structure):
       ('cluster_nodes', c_ptr), ('num_clusters', c_i64),
       ('facet_table', c_ptr), ('geo_const', c_ptr),
       ('chain_offsets', c_ptr), ('chain_elems', c_ptr), ('num_chains', c_i64),
+      ('layered_extent', c_i64),
   ]
 
 
@@ -116,6 +120,9 @@ SIGNATURES = {
     'sfem_cg_update_p': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_cg_update_r': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_cg_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+    'sfem_cg_update_r_layered': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
+                                 c_ptr, c_i32, c_i32, c_ptr],
+    'sfem_fold_layers': [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_cg_update_r_mean': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
                               c_ptr],
     'sfem_cg_update_xp_mean': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_dbl,

@@ -12,6 +12,7 @@ import os
 import numpy as np
 import torch
 
+from swirl_fem_amd import switches
 from swirl_fem_amd import _lib
 
 _DT = {torch.float32: _lib.SFEM_F32, torch.float64: _lib.SFEM_F64}
@@ -422,7 +423,8 @@ def _dptr(t):
 
 
 def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
-                    lambda0, lambda1, zero_range, dot_out=None):
+                    lambda0, lambda1, zero_range, dot_out=None,
+                    layered_extent=0):
   """Builds `sfem_helmholtz_args`; `part` = dict(geo_mode, geo, geo_elem,
   geo_index, elem_list), `host` = dict(dmat, weights, nodes) NumPy arrays
   (kept alive by the caller for the duration of the call)."""
@@ -440,13 +442,18 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
     enc, so = cl.enc, None
   ft = part.get('facet_table') if enc is not None else None
   ch = None
-  if ft is not None:
+  if layered_extent:
+    # same launches, layered table form; the layer plan was made for exactly
+    # these chain segments (or for none)
+    ft, so = part['layered_table'], None
+    ch = part.get('chains') if part.get('layered_chains') else None
+  elif ft is not None:
     so = None
     # chains walk scalar fields; a component-major vector field is walked
     # component by component
     if ((not vec or node_stride == 1) and
-        os.environ.get('SFEM_CHAIN', '1') != '0' and
-        (not vec or os.environ.get('SFEM_CHAIN_VECTOR', '1') != '0')):
+        switches.get('SFEM_CHAIN') != '0' and
+        (not vec or switches.get('SFEM_CHAIN_VECTOR') != '0')):
       ch = part.get('chains')        # (offsets, elems) int32 device tensors
   return _lib.HelmholtzArgs(
       u=u.data_ptr(), out=out.data_ptr(), enc=_dptr(enc),
@@ -471,7 +478,8 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       geo_const=_dptr(part.get('geo_const') if ft is not None else None),
       chain_offsets=_dptr(ch[0] if ch is not None else None),
       chain_elems=_dptr(ch[1] if ch is not None else None),
-      num_chains=0 if ch is None else ch[0].numel() - 1)
+      num_chains=0 if ch is None else ch[0].numel() - 1,
+      layered_extent=int(layered_extent))
 
 
 _CLUSTER_LIMITS = {}
@@ -490,21 +498,31 @@ def helmholtz_cluster_limits(P, dtype):
   return _CLUSTER_LIMITS[key]
 
 
-def helmholtz_kernel_name(real, P, ndim, scalar, geo_mode, part, mass):
-  """Mirror of `launch_helmholtz`'s choice (csrc/sfem_helmholtz.h)."""
+def helmholtz_kernel_name(real, P, ndim, scalar, geo_mode, part, mass,
+                          layered=False):
+  """Mirror of `launch_helmholtz`'s choice (csrc/sfem_helmholtz.h).  Facet
+  kernels: the name up to the addressing-width argument; `layered` (scalar
+  fields through `helmholtz_apply_layered`) appends `*, true>`: the last
+  template argument of those instantiations."""
   b = lambda v: 'true' if v else 'false'
   if part.get('facet_table') is not None:
     elem = ('sfem::BoxElem<%s, %d, %s>' % (real, P, b(mass)) if geo_mode == 5
             else 'sfem::FacetElem<%s, %d, %d, %s>' % (real, P, geo_mode,
                                                      b(mass)))
+    if layered:
+      if part.get('chains') is not None and part.get('layered_chains'):
+        return 'sfem::helmholtz_chain_kernel<%s, %d, %s, *, true>' % (
+            real, P, elem)
+      return 'sfem::helmholtz_facet_kernel<%s, %d, %s, true, *, true>' % (
+          real, P, elem)
     if (scalar and part.get('chains') is not None and
-        os.environ.get('SFEM_CHAIN', '1') != '0'):
+        switches.get('SFEM_CHAIN') != '0'):
       return 'sfem::helmholtz_chain_kernel<%s, %d, %s, ' % (real, P, elem)
     return 'sfem::helmholtz_facet_kernel<%s, %d, %s, %s, ' % (
         real, P, elem, b(scalar))
   if (real == 'float' and P == 12 and ndim == 3 and scalar and
       geo_mode in (1, 3) and part.get('cluster') is None and
-      not part.get('colored') and os.environ.get('SFEM_MFMA', '0') == '1'):
+      not part.get('colored') and switches.get('SFEM_MFMA') == '1'):
     return 'sfem::helmholtz_mfma_p12_kernel<%d, %s>' % (geo_mode, b(mass))
   if part.get('cluster') is not None:
     return 'sfem::helmholtz_cluster_kernel<%s, %d, %s, %d, %s>' % (
@@ -540,6 +558,58 @@ def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
                                                   _stream(dev)),
                  'sfem_helmholtz_apply')
   return out
+
+
+def helmholtz_apply_layered(u, ext, enc, parts, host, ndim, P, lambda0,
+                            lambda1, dot_out=None):
+  """`sfem_helmholtz_apply` with layered assembly: `ext` is the extended
+  output [N nodal values | layers] of the operator's layer plan (slots nobody
+  writes hold zero), `parts` carry `layered_table`.  Scalar fields; nothing is
+  cleared, no atomics are issued."""
+  dev = _dev(enc)
+  if u.dim() != 1 or not u.is_contiguous() or not ext.is_contiguous():
+    raise ValueError('layered assembly takes contiguous scalar fields')
+  if ext.dtype != u.dtype:
+    raise ValueError('u and the extended output differ in dtype')
+  host = {k: _host(v, u.dtype) for k, v in host.items()}
+  with torch.cuda.device(dev):
+    for part in parts:
+      args = _helmholtz_args(u, ext, enc, part, host, ndim, P, enc.shape[0],
+                             u.shape[0], lambda0, lambda1, (0, 0), dot_out,
+                             layered_extent=ext.numel())
+      _lib.check(_lib.load().sfem_helmholtz_apply(ctypes.byref(args),
+                                                  _stream(dev)),
+                 'sfem_helmholtz_apply')
+  return ext
+
+
+def _layer_arrays(layers):
+  """(len, off) int64 ctypes arrays of a layer list [(length, offset), ...]."""
+  n = len(layers)
+  arr = ctypes.c_int64 * max(n, 1)
+  return (arr(*[int(l[0]) for l in layers]) if n else arr(0),
+          arr(*[int(l[1]) for l in layers]) if n else arr(0), n)
+
+
+def cg_update_r_layered(r, ap_ext, layers, scalars, fuse_rr):
+  """r -= alpha (Ap assembled from its layers) (+ gamma_new += r.r)."""
+  dev = _dev(r, ap_ext, scalars)
+  ln, off, n = _layer_arrays(layers)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_r_layered(
+        _ptr(r), _ptr(ap_ext), r.numel(), ln, off, n, _ptr(scalars),
+        int(fuse_rr), _dtype_code(r), _stream(dev)), 'sfem_cg_update_r_layered')
+
+
+def fold_layers(ext, count, layers):
+  """ext[:count] += its layers (in place); returns the view ext[:count]."""
+  dev = _dev(ext)
+  ln, off, n = _layer_arrays(layers)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_fold_layers(
+        _ptr(ext), int(count), ln, off, n, _dtype_code(ext), _stream(dev)),
+        'sfem_fold_layers')
+  return ext[:count]
 
 
 def stokes_setup(invjac, jacdet, weights_nd):

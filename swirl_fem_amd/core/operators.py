@@ -26,6 +26,7 @@ import os
 import numpy as np
 import torch
 
+from swirl_fem_amd import switches
 from swirl_fem_amd import _ops
 
 MAX_FUSED_P = 12
@@ -110,7 +111,7 @@ def chain_segment_length(num_elements):
   MI355X with fewer than ~4 rounds of workgroups (16^3 elements in chains of
   8 are 512 workgroups: the Taylor-Green step at 16^3 went from 33 to 50 ms).
   `SFEM_CHAIN_LEN` overrides."""
-  env = os.environ.get('SFEM_CHAIN_LEN')
+  env = switches.get('SFEM_CHAIN_LEN')
   if env:
     return max(1, int(env))
   return max(1, min(8, num_elements // 16384))
@@ -206,13 +207,13 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
       # (P >= 9 has chain instantiations for box / affine elements only:
       # FacetElem::CHAINS; the library refuses the others)
       if seg_len > 1 and (P <= 8 or (
-          os.environ.get('SFEM_CHAIN_HI') == '1' and
+          switches.get('SFEM_CHAIN_HI') == '1' and
           mode in (_GEO_BOX, _GEO_AFFINE))):
         new['chains'] = facet_chains(mesh.elements, ids, P, seg_len)
         new['chain_len'] = seg_len
     out.append(new)
 
-  use_box = os.environ.get('SFEM_BOX', '1') != '0'
+  use_box = switches.get('SFEM_BOX') != '0'
   for part in parts:
     ids = every if 'elem_list' not in part else part['elem_list'].long()
     good = ok[ids]
@@ -232,6 +233,118 @@ def _facet_parts(fespace, parts, mask, multiplicity, coef):
       add(part, ids[good], mode, True)
     add(part, ids[~good], mode, False)
   return out
+
+
+@dataclasses.dataclass(eq=False)
+class LayerPlan:
+  """Layered assembly of an operator's facet launches (`build_layer_plan`).
+
+  `layers[k] = (length, offset)`: layer k + 1 of the extended output
+  [N nodal values | layer 1 | layer 2 | ...] covers the nodes [0, length) and
+  starts at element `offset`; `extent` = size of the extended vector;
+  `parts` = the launches with their `layered_table`; `written` = number of
+  slots the launches store per apply (layer 0 included)."""
+  layers: list
+  extent: int
+  parts: list
+  written: int
+  num_nodes: int
+
+
+def build_layer_plan(facet_parts, num_elements, num_nodes, P):
+  """Gives every (element, facet) that writes a facet of the mesh a LAYER of
+  its own for it, so that the direct-stiffness sum (reference
+  core/gather_scatter.py:130-133) needs neither atomics nor a cleared range:
+  the kernels store every result plainly, the consumer adds the layers of a
+  node in layer order (`sfem_cg_update_r_layered`, `sfem_fold_layers`).
+
+  Writers of a facet: every element that holds it, except -- inside a chain
+  segment -- the element that hands its last face (and that face's edges and
+  vertices) on to its successor, which stores the sum.  Layer = rank of the
+  writer among the writers of the facet (0 = the nodal vector itself).  The
+  refiner numbers vertices, then edge, face and element interiors, so the
+  nodes with k + 1 or more writers are a prefix [0, n_k): layer k is an array
+  of n_k values (config 2: n_1 = 37 % of N, n_2 = n_3 = 5 %, n_4.. = 0.3 %).
+  Slots nobody writes (a facet with fewer writers than the layer's other
+  facets) stay zero from the allocation.
+
+  Returns None when the launches do not cover every element from a facet table
+  (index-row elements accumulate with atomics), when a stride does not fit
+  the 16 bits of the layered table, or when a facet has more than
+  SFEM_MAX_LAYERS + 1 writers."""
+  from swirl_fem_amd import _lib
+  if not facet_parts or any('facet_table' not in q for q in facet_parts):
+    return None
+  tab = facet_parts[0]['facet_table']
+  dev = tab.device
+  E, N = num_elements, num_nodes
+  use_chains = switches.get('SFEM_CHAIN') != '0'
+  has_succ = torch.zeros(E, dtype=torch.bool, device=dev)
+  covered = torch.zeros(E, dtype=torch.int32, device=dev)
+  for q in facet_parts:
+    if q['facet_table'] is not tab:
+      return None
+    if 'elem_list' in q:
+      covered[q['elem_list'].long()] += 1
+    else:
+      covered += 1
+    if 'chains' in q and use_chains:
+      off, elems = q['chains']
+      succ = torch.ones(elems.numel(), dtype=torch.bool, device=dev)
+      succ[off[1:].long() - 1] = False           # last element of a segment
+      has_succ[elems.long()] = succ
+  if not bool((covered == 1).all()):
+    return None
+  t = tab.to(torch.int64)                                    # (E, 27, 4)
+  code = t[..., 0] & 0xFFFFFFFF
+  id0, dflag = code & 0x3FFFFFFF, code & 0x80000000
+  strides = t[..., 1:]                                       # (E, 27, 3)
+  if int(strides[..., 1:].abs().max()) >= 32768:
+    return None
+  f = torch.arange(27, device=dev)
+  inner = torch.stack([f // 9 == 1, (f // 3) % 3 == 1, f % 3 == 1], dim=1)
+  span = strides * (P - 3) * inner[None].to(torch.int64)     # (index - 1) max
+  lo = id0 + span.clamp(max=0).sum(-1)                       # smallest node id
+  hi = id0 + span.clamp(min=0).sum(-1) + 1                   # largest + 1
+  count = torch.where(inner, P - 2, 1).prod(dim=1)           # nodes per facet
+  writer = torch.ones((E, 27), dtype=torch.bool, device=dev)
+  writer[:, 18:] &= ~has_succ[:, None]                       # a-class LAST
+  idx = torch.nonzero(writer.reshape(-1)).reshape(-1)
+  key, perm = torch.sort(lo.reshape(-1)[idx], stable=True)
+  first = torch.ones_like(key, dtype=torch.bool)
+  first[1:] = key[1:] != key[:-1]
+  pos = torch.arange(key.numel(), device=dev)
+  start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), 0).values
+  layer = torch.zeros(E * 27, dtype=torch.int64, device=dev)
+  layer[idx[perm]] = pos - start
+  nl = int(layer.max())
+  if nl > _lib.SFEM_MAX_LAYERS:
+    return None
+  hi_w = torch.where(writer, hi, torch.zeros_like(hi)).reshape(-1)
+  lens = [int(hi_w[layer == k].max()) for k in range(1, nl + 1)]
+  for k in range(nl - 2, -1, -1):
+    lens[k] = max(lens[k], lens[k + 1])
+  pad = lambda v: (v + 3) // 4 * 4                 # 16 bytes in fp32 and fp64
+  lens = [pad(v) for v in lens]
+  offs, at = [], pad(N)
+  for v in lens:
+    offs.append(at)
+    at += v
+  extent = at
+  if extent > 0x3FFFFFFF:
+    return None
+  base = torch.tensor([0] + offs, dtype=torch.int64, device=dev)
+  pos_out = (base[layer].reshape(E, 27) + id0) | dflag
+  packed = (strides[..., 1] & 0xFFFF) | ((strides[..., 2] & 0xFFFF) << 16)
+  wrap = lambda v: ((v + (1 << 31)) % (1 << 32) - (1 << 31)).to(torch.int32)
+  tab2 = torch.stack([t[..., 0].to(torch.int32), wrap(pos_out),
+                      strides[..., 0].to(torch.int32), wrap(packed)],
+                     dim=-1).contiguous()
+  written = int((writer.to(torch.int64) * count[None]).sum())
+  parts = [dict(q, layered_table=tab2, layered_chains=use_chains and
+                'chains' in q) for q in facet_parts]
+  return LayerPlan(layers=list(zip(lens, offs)), extent=extent, parts=parts,
+                   written=written, num_nodes=N)
 
 
 def _cluster_limits(fespace):
@@ -274,6 +387,7 @@ class HelmholtzOperator:
   # fields), or None: see `_facet_parts`
   facet_parts: list | None = None
   _vector_parts: list | None = None   # launches of vector fields (`_parts_for`)
+  _layer_plan: object = None          # LayerPlan, False = none (`layer_plan`)
 
   @classmethod
   def create(cls, fespace, dirichlet_mask=None, geometry='auto',
@@ -300,7 +414,7 @@ class HelmholtzOperator:
     requested = assembly
     if assembly == 'auto':
       assembly = ('cluster' if _cluster_limits(fespace) is not None and
-                  os.environ.get('SFEM_CLUSTER', '0') == '1' else 'atomic')
+                  switches.get('SFEM_CLUSTER') == '1' else 'atomic')
     elif assembly == 'cluster' and _cluster_limits(fespace) is None:
       raise NotImplementedError('cluster assembly needs ndim = 3, P = 4..8')
     mesh = fespace.mesh
@@ -382,7 +496,7 @@ class HelmholtzOperator:
 
     if (assembly == 'atomic' and mesh.ndim == 3 and
         mesh.gridpoints_1d.num_points <= 8 and      # one wave per element
-        os.environ.get('SFEM_SORTED_SCATTER', '1') != '0'):
+        switches.get('SFEM_SORTED_SCATTER') != '0'):
       # 3D: most slots of an element are shared; issue their atomics in node
       # order (better coalesced, see the kernel)
       so = shared_slot_order(enc)
@@ -391,7 +505,7 @@ class HelmholtzOperator:
     facet_parts = None
     if (assembly == 'atomic' and mesh.ndim == 3 and
         mesh.gridpoints_1d.num_points in FACET_P and
-        os.environ.get('SFEM_FACET', '1') != '0'):
+        switches.get('SFEM_FACET') != '0'):
       facet_parts = _facet_parts(fespace, parts, mask, plan.multiplicity, coef)
     host = {'dmat': fespace.interpolator._differentiation_matrix_1d(),
             'weights': np.asarray(fespace.quadrature.weights),
@@ -441,8 +555,9 @@ class HelmholtzOperator:
             self.fespace.mesh.assembly_plan().multiplicity, parts)
       facet = (None if self.facet_parts is None
                else restrict(self.facet_parts, keep))
+      # (each half covers part of the mesh only: no layer plan)
       halves.append(dataclasses.replace(self, parts=parts, facet_parts=facet,
-                                        _vector_parts=None))
+                                        _vector_parts=None, _layer_plan=False))
     return tuple(halves)
 
   def apply(self, u, lambda0=0.0, lambda1=1.0, out=None, *, zero=True,
@@ -467,6 +582,46 @@ class HelmholtzOperator:
         u, out, self.enc, self._parts_for(u), self.host, mesh.ndim,
         mesh.gridpoints_1d.num_points, lambda0, lambda1,
         self.zero_range if zero else (0, 0), dot_out)
+
+  def layer_plan(self):
+    """The `LayerPlan` of this operator's facet launches (made on first use),
+    or None: see `build_layer_plan`; `SFEM_LAYERED=0` switches it off."""
+    if self._layer_plan is None:
+      plan = None
+      if (self.facet_parts is not None and
+          switches.get('SFEM_LAYERED') != '0'):
+        mesh = self.fespace.mesh
+        plan = build_layer_plan(self.facet_parts, mesh.num_elements,
+                                mesh.num_nodes, mesh.gridpoints_1d.num_points)
+      self._layer_plan = plan if plan is not None else False
+    return self._layer_plan or None
+
+  def new_extended(self):
+    """A zeroed extended output for `apply_layered` (slots that no element
+    writes must stay zero: keep one such buffer per consumer)."""
+    plan = self.layer_plan()
+    return torch.zeros(plan.extent, dtype=self.fespace.dtype,
+                       device=self.enc.device)
+
+  def apply_layered(self, u, ext, lambda0=0.0, lambda1=1.0, *, dot_out=None):
+    """`apply` for a scalar field with layered assembly: the unassembled
+    contributions go to `ext` (from `new_extended`) as plain stores; the
+    assembled value of node i is `ext[i]` plus its layers
+    (`_ops.fold_layers(ext, N, plan.layers)`, or inside the consumer:
+    `_ops.cg_update_r_layered`).  Dirichlet rows are zero in every layer."""
+    plan = self.layer_plan()
+    if plan is None:
+      raise NotImplementedError('this operator has no layer plan')
+    mesh = self.fespace.mesh
+    if tuple(u.shape) != (mesh.num_nodes,):
+      raise ValueError(f'expected ({mesh.num_nodes},) nodal values, got '
+                       f'{tuple(u.shape)}')
+    if tuple(ext.shape) != (plan.extent,):
+      raise ValueError(f'expected an extended output of {plan.extent} values')
+    return _ops.helmholtz_apply_layered(
+        u.to(self.fespace.dtype).contiguous(), ext, self.enc, plan.parts,
+        self.host, mesh.ndim, mesh.gridpoints_1d.num_points, lambda0, lambda1,
+        dot_out)
 
   def _parts_for(self, u):
     """Facet-table launches for scalar / component-major fields (the kernels
@@ -509,19 +664,26 @@ class HelmholtzOperator:
     it also offers `apply_with_dot(u, partials)` (fused p.Ap)."""
     return FusedLinearOperator(self, lambda0, lambda1)
 
-  def bytes_per_apply(self, lambda0=0.0, ncomp=1):
+  def bytes_per_apply(self, lambda0=0.0, ncomp=1, layered=False):
     """Bytes one `apply` HAS to move, launch by launch (what the roofline of
     bench.py divides by): the field in and out once (`2 s N ncomp`), the
     connectivity each launch reads -- 432 bytes per element from a facet
     table (+ 4 per element of a chain list), or `4 n` per element of index
     rows plus `2 S` of sorted shared slots -- and the geometry it reads: 64
     bytes (affine / box constants) or `24 s` (multilinear coefficients) per
-    element, `(6 or 7) s n` for elements with stored factors."""
+    element, `(6 or 7) s n` for elements with stored factors.  `layered`
+    (`apply_layered`): the field in once, and every slot the launches store
+    (`LayerPlan.written`: the nodal values plus the further layers of shared
+    facets) instead of the field out once."""
     mesh = self.fespace.mesh
     E, n = mesh.elements.shape
     s = 8 if self.fespace.dtype == torch.float64 else 4
     total = 2 * s * mesh.num_nodes * ncomp
     parts = self.facet_parts if self.facet_parts is not None else self.parts
+    if layered:
+      plan = self.layer_plan()
+      total = s * (mesh.num_nodes + plan.written)
+      parts = plan.parts
     for part in parts:
       count = part['elem_list'].numel() if 'elem_list' in part else E
       mode = part['geo_mode']
@@ -540,18 +702,20 @@ class HelmholtzOperator:
       total += count * (conn + geo)
     return total
 
-  def kernel_name(self, lambda0=0.0, lambda1=1.0, ncomp=1):
-    """Name(s) of the kernel instantiation(s) `apply` launches, as they appear
-    in a rocprofv3 kernel trace (one per geometry kind present)."""
+  def kernel_name(self, lambda0=0.0, lambda1=1.0, ncomp=1, layered=False):
+    """Name(s) of the kernel instantiation(s) `apply` (`apply_layered`)
+    launches, as they appear in a rocprofv3 kernel trace (one per geometry
+    kind present)."""
     mesh = self.fespace.mesh
     real = 'double' if self.fespace.dtype == torch.float64 else 'float'
     P = mesh.gridpoints_1d.num_points
     names = []
-    for part in (self.parts if self.facet_parts is None
-                 else self.facet_parts):
+    parts = (self.layer_plan().parts if layered else
+             self.parts if self.facet_parts is None else self.facet_parts)
+    for part in parts:
       gm = part['geo_mode']
       names.append(_ops.helmholtz_kernel_name(
-          real, P, mesh.ndim, ncomp == 1, gm, part, lambda0 != 0))
+          real, P, mesh.ndim, ncomp == 1, gm, part, lambda0 != 0, layered))
     return ' + '.join(sorted(set(names)))
 
 
@@ -560,6 +724,7 @@ class FusedLinearOperator:
 
   def __init__(self, op, lambda0, lambda1):
     self.op, self.lambda0, self.lambda1 = op, lambda0, lambda1
+    self._ext = None
 
   def __call__(self, u):
     return self.op.apply(u, self.lambda0, self.lambda1)
@@ -567,6 +732,29 @@ class FusedLinearOperator:
   def apply_with_dot(self, u, partials):
     """Returns A(u) and accumulates partial sums of u . A(u)."""
     return self.op.apply(u, self.lambda0, self.lambda1, dot_out=partials)
+
+  def layer_plan(self):
+    """The operator's layer plan if a Krylov iteration gains from it: the
+    apply loses its atomics and the clearing of the shared range, the
+    `r -= alpha Ap` that adds the layers up reads 0.5 GB more at config 2
+    (`scripts/time_layered.py`, ms per CG iteration atomic -> layered: box
+    1.556 -> 1.523, multilinear 1.769 -> 1.751, p = 11 fp32 3.249 -> 3.188;
+    elements that stream stored factors 2.710 -> 2.738: those keep the
+    atomics unless SFEM_LAYERED=force)."""
+    plan = self.op.layer_plan()
+    if plan is not None and switches.get('SFEM_LAYERED') != 'force' and any(
+        q['geo_mode'] == _GEO_POINT for q in plan.parts):
+      return None
+    return plan
+
+  def apply_layered_with_dot(self, u, partials):
+    """A(u) in layered form (an extended vector owned by this object, see
+    `HelmholtzOperator.apply_layered`) + partial sums of u . A(u): for
+    consumers that add the layers up themselves (`linalg.cg`)."""
+    if self._ext is None:
+      self._ext = self.op.new_extended()
+    return self.op.apply_layered(u, self._ext, self.lambda0, self.lambda1,
+                                 dot_out=partials)
 
 
 # ---------------------------------------------------------------------------
@@ -731,8 +919,8 @@ class StokesDivGrad:
             'interp': pspace.interpolator._interpolation_matrix_1d()}
     facet_parts = None
     if (mesh.ndim == 3 and mesh.gridpoints_1d.num_points in STOKES_FACET_P and
-        os.environ.get('SFEM_FACET', '1') != '0' and
-        os.environ.get('SFEM_STOKES_FACET', '1') != '0'):
+        switches.get('SFEM_FACET') != '0' and
+        switches.get('SFEM_STOKES_FACET') != '0'):
       facet_parts = cls._facet_parts(mesh, parts, mask, plan.multiplicity)
     return cls(vspace=vspace, pspace=pspace, parts=parts, enc=enc, penc=penc,
                host=host, zero_range=plan.zero_range,
@@ -750,10 +938,10 @@ class StokesDivGrad:
     if not bool(ok.any()):
       return None
     seg_len = chain_segment_length(E)
-    if os.environ.get('SFEM_CHAIN', '1') == '0':
+    if switches.get('SFEM_CHAIN') == '0':
       seg_len = 1
     every = torch.arange(E, device=ok.device)
-    use_box = os.environ.get('SFEM_BOX', '1') != '0'
+    use_box = switches.get('SFEM_BOX') != '0'
     out = []
     for part in parts:
       ids = every if 'elem_list' not in part else part['elem_list'].long()
@@ -787,7 +975,7 @@ class StokesDivGrad:
     divergence through them regardless (tests)."""
     if self.facet_parts is None or not _ops.is_component_major(field):
       return self.parts
-    if not div or os.environ.get('SFEM_STOKES_FACET_DIV', 'box') == 'all':
+    if not div or switches.get('SFEM_STOKES_FACET_DIV') == 'all':
       return self.facet_parts
     if self._div_parts is None:
       # (fp32: the box divergence measures 0.20 against 0.18 ms on index rows
@@ -806,7 +994,7 @@ class StokesDivGrad:
   @staticmethod
   def _order(mesh, enc):
     if (mesh.ndim == 3 and mesh.gridpoints_1d.num_points <= 8 and
-        os.environ.get('SFEM_SORTED_SCATTER', '1') != '0'):
+        switches.get('SFEM_SORTED_SCATTER') != '0'):
       return shared_slot_order(enc)
     return None
 

@@ -717,6 +717,144 @@ cg_update_xp_mean_kernel(T* __restrict__ x, T* __restrict__ p,
   }
 }
 
+// Layered assembly (sfem_helmholtz_args.layered_extent): `ap` is an extended
+// vector [ N nodal values | layer 1 | layer 2 | ... ]; layer k covers the nodes
+// [0, len[k]) and starts at element off[k].  The operator wrote every
+// contribution of a shared node to a layer of its own with a plain store; here,
+// where Ap is streamed anyway, they are added up in layer order (a fixed order:
+// the result is bitwise reproducible) -- no atomics, no cleared range.
+struct LayerDesc {
+  int nl;
+  int64_t len[SFEM_MAX_LAYERS];   // multiples of the 16-byte vector width
+  int64_t off[SFEM_MAX_LAYERS];
+};
+
+template <typename T, bool NT>
+__device__ __forceinline__ typename Vec16<T>::type add_layers(
+    typename Vec16<T>::type aa, const T* __restrict__ ap, int64_t i,
+    const LayerDesc& ld) {
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  for (int k = 0; k < ld.nl; ++k) {
+    if (i * VN >= ld.len[k]) break;            // lengths do not increase
+    const V l = ld16<T, NT>(reinterpret_cast<const V*>(ap + ld.off[k]) + i);
+#pragma unroll
+    for (int c = 0; c < VN; ++c)
+      reinterpret_cast<T*>(&aa)[c] += vget<T>(l, c);
+  }
+  return aa;
+}
+
+template <typename T, bool FUSE_RR, bool NT, bool STRIPED>
+__global__ void __launch_bounds__(512)
+cg_update_r_layered_kernel(T* __restrict__ r, const T* __restrict__ ap,
+                           int64_t count, LayerDesc ld,
+                           double* __restrict__ scalars) {
+  if (scalars[7] != 0.0) return;
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const T alpha = (T)(scalars[0] / scalars[1]);
+  const int64_t nvec = count / VN;
+  V* rv = reinterpret_cast<V*>(r);
+  const V* apv = reinterpret_cast<const V*>(ap);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride) {
+    V rr = ld16<T, NT>(&rv[i]);
+    const V aa = add_layers<T, NT>(ld16<T, NT>(&apv[i]), ap, i, ld);
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      T* re = reinterpret_cast<T*>(&rr) + c;
+      *re -= alpha * vget<T>(aa, c);
+      if (FUSE_RR) acc += (double)*re * (double)*re;
+    }
+    st16<T, NT>(rr, &rv[i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
+    T a = ap[i];
+    for (int k = 0; k < ld.nl; ++k)
+      if (i < ld.len[k]) a += ap[ld.off[k] + i];
+    const T rn = r[i] - alpha * a;
+    r[i] = rn;
+    if (FUSE_RR) acc += (double)rn * (double)rn;
+  }
+  if (FUSE_RR) {
+    const double total = block_sum(acc);
+    if (threadIdx.x == 0)
+      unsafeAtomicAdd(STRIPED ? &scalars[SFEM_CG_NSCALARS_NAMED +
+                                         (blockIdx.x & (SFEM_CG_RR_SLOTS - 1))]
+                              : &scalars[2], total);
+  }
+}
+
+// out[i] += layer_1[i] + layer_2[i] + ...  for i < len[0]: the assembled vector
+// for consumers that do not add the layers up themselves.
+template <typename T>
+__global__ void __launch_bounds__(512)
+fold_layers_kernel(T* __restrict__ out, int64_t count, LayerDesc ld) {
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
+  const int64_t top = ld.nl ? (ld.len[0] < count ? ld.len[0] : count) : 0;
+  const int64_t nvec = top / VN;
+  V* ov = reinterpret_cast<V*>(out);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += stride)
+    ov[i] = add_layers<T, false>(ov[i], out, i, ld);
+  if (blockIdx.x == 0 && threadIdx.x < top - nvec * VN) {
+    const int64_t i = nvec * VN + threadIdx.x;
+    T a = out[i];
+    for (int k = 0; k < ld.nl; ++k)
+      if (i < ld.len[k]) a += out[ld.off[k] + i];
+    out[i] = a;
+  }
+}
+
+static int make_layer_desc(const char* who, const int64_t* layer_len,
+                           const int64_t* layer_off, int num_layers,
+                           int64_t count, int vn, LayerDesc* ld) {
+  SFEM_REQUIRE(num_layers >= 0 && num_layers <= SFEM_MAX_LAYERS,
+               "%s: %d layers (at most %d)", who, num_layers, SFEM_MAX_LAYERS);
+  SFEM_REQUIRE(num_layers == 0 || (layer_len && layer_off),
+               "%s: null layer description", who);
+  ld->nl = num_layers;
+  for (int k = 0; k < num_layers; ++k) {
+    SFEM_REQUIRE(layer_len[k] >= 0 && layer_len[k] % vn == 0 &&
+                     layer_off[k] >= count && layer_off[k] % vn == 0 &&
+                     (k == 0 || layer_len[k] <= layer_len[k - 1]),
+                 "%s: layer %d (length %lld, offset %lld) must be 16-byte "
+                 "aligned, behind the %lld nodal values and not longer than "
+                 "the layer before it", who, k, (long long)layer_len[k],
+                 (long long)layer_off[k], (long long)count);
+    ld->len[k] = layer_len[k];
+    ld->off[k] = layer_off[k];
+  }
+  return SFEM_OK;
+}
+
+template <typename T>
+static void launch_update_r_layered(int fuse_rr, bool nt, int grid,
+                                    hipStream_t st, T* rr, const T* aa,
+                                    int64_t count, const LayerDesc& ld,
+                                    double* scalars) {
+#define SFEM_UPDATE_RL(FUSE, NTV, STR)                                        \
+  hipLaunchKernelGGL((cg_update_r_layered_kernel<T, FUSE, NTV, STR>),         \
+                     dim3(grid), dim3(512), 0, st, rr, aa, count, ld, scalars)
+  if (fuse_rr == 2) {
+    if (nt) SFEM_UPDATE_RL(true, true, true);
+    else SFEM_UPDATE_RL(true, false, true);
+  } else if (fuse_rr) {
+    if (nt) SFEM_UPDATE_RL(true, true, false);
+    else SFEM_UPDATE_RL(true, false, false);
+  } else {
+    if (nt) SFEM_UPDATE_RL(false, true, false);
+    else SFEM_UPDATE_RL(false, false, false);
+  }
+#undef SFEM_UPDATE_RL
+}
+
 template <typename T>
 static void launch_update_r(int fuse_rr, bool nt, int grid, hipStream_t stream,
                             T* r, const T* ap, int64_t count, double* scalars) {
@@ -1242,6 +1380,56 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
                                   : reduce_grid(count, 512 * 2);
     launch_update_r<T>(fuse_rr, streams_past_caches(count, sizeof(T)), grid,
                        as_stream(stream), (T*)r, (const T*)ap, count, scalars);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
+                             const int64_t* layer_len,
+                             const int64_t* layer_off, int num_layers,
+                             double* scalars, int fuse_rr, int dtype,
+                             sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_r_layered: bad arguments");
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(r && ap_ext, "sfem_cg_update_r_layered: null pointer");
+  SFEM_REQUIRE(fuse_rr >= 0 && fuse_rr <= 2,
+               "sfem_cg_update_r_layered: bad fuse_rr");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_cg_update_r_layered: unknown dtype %d", dtype);
+  LayerDesc ld;
+  const int rc = make_layer_desc("sfem_cg_update_r_layered", layer_len,
+                                 layer_off, num_layers, count,
+                                 dtype == SFEM_F64 ? 2 : 4, &ld);
+  if (rc != SFEM_OK) return rc;
+  DISPATCH_DTYPE(dtype, {
+    const int grid = fuse_rr == 2 ? stream_grid(count, 512 * 2)
+                                  : reduce_grid(count, 512 * 2);
+    launch_update_r_layered<T>(fuse_rr, streams_past_caches(count, sizeof(T)),
+                               grid, as_stream(stream), (T*)r,
+                               (const T*)ap_ext, count, ld, scalars);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_fold_layers(void* out_ext, int64_t count, const int64_t* layer_len,
+                     const int64_t* layer_off, int num_layers, int dtype,
+                     sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0, "sfem_fold_layers: negative count");
+  if (count == 0 || num_layers == 0) return SFEM_OK;
+  SFEM_REQUIRE(out_ext, "sfem_fold_layers: null pointer");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_fold_layers: unknown dtype %d", dtype);
+  LayerDesc ld;
+  const int rc = make_layer_desc("sfem_fold_layers", layer_len, layer_off,
+                                 num_layers, count, dtype == SFEM_F64 ? 2 : 4,
+                                 &ld);
+  if (rc != SFEM_OK) return rc;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((fold_layers_kernel<T>),
+                       dim3(stream_grid(ld.len[0], 512 * 2)), dim3(512), 0,
+                       as_stream(stream), (T*)out_ext, count, ld);
   });
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;

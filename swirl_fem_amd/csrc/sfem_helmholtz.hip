@@ -244,6 +244,7 @@ struct HelmholtzCall {
   const int32_t* chain_offsets = nullptr;
   const int32_t* chain_elems = nullptr;
   int64_t num_chains = 0;
+  int64_t layered_extent = 0;
 };
 
 template <typename T>
@@ -277,6 +278,12 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
     fp.dot_out = prm.dot_out;
     fp.chain_off = c.chain_offsets;
     fp.chain_elems = c.chain_elems;
+    fp.layered = c.layered_extent > 0;
+    if (fp.layered)       // positions in the extended vector decide the
+      return dispatch_helmholtz_facet<T>(   // addressing width, scalar only
+          fp, c.P, c.geo_mode,
+          c.chain_offsets ? c.num_chains : c.num_elements, c.layered_extent,
+          prm.dmat_host, prm.weights_host, prm.nodes_host, stream);
     if (c.chain_offsets && c.ncomp > 1) {
       // component-major vector field: every component is a scalar field of
       // its own strip, walked by the (scalar) chain kernel
@@ -461,6 +468,16 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
     c.facet_table = a->facet_table;
     c.geo_const = a->geo_const;
     c.num_nodes = a->num_nodes;
+    if (a->layered_extent) {
+      SFEM_REQUIRE(a->layered_extent >= a->num_nodes &&
+                       a->layered_extent <= SFEM_IDX_MASK,
+                   "sfem_helmholtz_apply: layered_extent must cover the "
+                   "nodal values and stay below 2^30");
+      SFEM_REQUIRE(a->ncomp == 1 && a->zero_end == a->zero_begin,
+                   "sfem_helmholtz_apply: layered assembly takes scalar "
+                   "fields and clears nothing");
+      c.layered_extent = a->layered_extent;
+    }
     if (a->chain_offsets) {
       SFEM_REQUIRE(a->chain_elems && a->num_chains > 0 &&
                        (a->ncomp == 1 || a->node_stride == 1),
@@ -471,6 +488,8 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
       c.num_chains = a->num_chains;
     }
   }
+  SFEM_REQUIRE(!a->layered_extent || a->facet_table,
+               "sfem_helmholtz_apply: layered assembly needs a facet table");
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
 }

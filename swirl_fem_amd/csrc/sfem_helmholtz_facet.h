@@ -67,7 +67,19 @@ struct FacetParams {
   int ncomp;
   T lambda0, lambda1;
   double* dot_out;
+  // Layered assembly (no atomics, no cleared range, bitwise reproducible):
+  // `tab` is then the (E, 27, 4) table in its layered form
+  //   x = id0 | flags (as above: where the element READS),
+  //   y = position in the EXTENDED output (layer base + id0) | DIRICHLET flag,
+  //   z = sa, w = (si & 0xffff) | (sj << 16)
+  // and `out` an extended vector [ N nodal values | layer 1 | layer 2 | ... ]:
+  // every (element, facet) that writes has a layer of its own for that facet,
+  // so all results leave as plain stores; the consumer adds the layers up
+  // (`sfem_cg_update_r_layered`, `sfem_fold_layers`).  Scalar fields.
+  int layered;
 };
+
+constexpr uint32_t FACET_SKIP = 0x40000000u;   // layered: class is not written
 
 // Where node (x, y, z) of an element sits in its LDS copy (in words of T), and
 // the shape of the workgroup: one element, ceil(P^2 / 64) waves.
@@ -262,11 +274,13 @@ __device__ __forceinline__ T* facet_node(T* base, uint32_t code) {
 // Per-lane connectivity of one element: the lane's nodes in the three slice
 // classes (FIRST a = 0, INNER 0 < a < P-1, LAST a = P-1) and the a-stride of
 // the INNER facet.  Flags ride in the two top bits of t[].
-template <int P>
+template <int P, bool LAY = false>
 struct FacetLane {
   typedef int32_t I4 __attribute__((ext_vector_type(4)));
   struct Raw { I4 en[3]; };   // the lane's three table entries as loaded
   uint32_t t[3];
+  uint32_t to[LAY ? 3 : 1];   // layered: where the lane WRITES (| DIRICHLET,
+                              // | FACET_SKIP), same strides as t[]
   int32_t sa;
   static __device__ __forceinline__ int cls(int a) {
     return a == 0 ? 0 : (a == P - 1 ? 2 : 1);
@@ -280,11 +294,23 @@ struct FacetLane {
     for (int c = 0; c < 3; ++c) raw.en[c] = row[c * 9 + lc];
   }
   __device__ __forceinline__ void finish(const Raw& raw, int i, int j) {
+    if constexpr (LAY) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      t[c] = (uint32_t)raw.en[c].x + (uint32_t)__mul24(raw.en[c].z, i - 1) +
-             (uint32_t)__mul24(raw.en[c].w, j - 1);
-    sa = raw.en[1].y;
+      for (int c = 0; c < 3; ++c) {
+        const int32_t si = (raw.en[c].w << 16) >> 16, sj = raw.en[c].w >> 16;
+        const uint32_t d = (uint32_t)__mul24(si, i - 1) +
+                           (uint32_t)__mul24(sj, j - 1);
+        t[c] = (uint32_t)raw.en[c].x + d;
+        to[c] = (uint32_t)raw.en[c].y + d;
+      }
+      sa = raw.en[1].z;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        t[c] = (uint32_t)raw.en[c].x + (uint32_t)__mul24(raw.en[c].z, i - 1) +
+               (uint32_t)__mul24(raw.en[c].w, j - 1);
+      sa = raw.en[1].y;
+    }
   }
   __device__ __forceinline__ void load(const int32_t* tab, int64_t e, int i,
                                        int j) {
@@ -298,15 +324,21 @@ struct FacetLane {
                   : (a == P - 1 ? t[2] : t[1] + (uint32_t)(sa * (a - 1)));
   }
   __device__ __forceinline__ uint32_t flags(int a) const {
-    return t[cls(a)];
+    return LAY ? to[cls(a)] : t[cls(a)];
+  }
+  // layered: position | flags of the lane's result for slice a
+  __device__ __forceinline__ uint32_t ocode(int a) const {
+    return a == 0 ? to[0]
+                  : (a == P - 1 ? to[LAY ? 2 : 0]
+                                : to[LAY ? 1 : 0] + (uint32_t)(sa * (a - 1)));
   }
 };
 
 // Direct-stiffness summation of one element's results `acc` (slot layout:
 // lane (i, j) holds nodes (a, i, j)), in two halves so that a kernel can issue
 // other memory traffic between them.  Head: Dirichlet rows and u . out.
-template <typename T, int P>
-__device__ __forceinline__ void facet_scatter_head(const FacetLane<P>& fl,
+template <typename T, int P, bool LAY = false>
+__device__ __forceinline__ void facet_scatter_head(const FacetLane<P, LAY>& fl,
                                                    T (&acc)[P],
                                                    const T (&ua)[P],
                                                    bool want_dot,
@@ -334,11 +366,7 @@ __device__ __forceinline__ void facet_scatter_tail(
 #pragma unroll
       for (int a = 0; a < P; ++a)
         if (FacetLane<P>::cls(a) == c) {
-#if SFEM_FACET_TIMING == 5
-          asm volatile("" :: "v"(acc[a]));
-#else
           *facet_node<T, OFF32>(og, fl.code(a)) = acc[a];
-#endif
         }
     }
   }
@@ -356,20 +384,62 @@ __device__ __forceinline__ void facet_scatter_tail(
     const uint32_t w = slots[q];
     if (w != 0xFFFFu) {
       const uint32_t code = codes[w];
-#if SFEM_FACET_TIMING == 7        // timing only: no edge / vertex atomics
-      if ((int)threadIdx.x >= (P - 2) * (P - 2)) continue;
-#elif SFEM_FACET_TIMING == 8      // timing only: no face atomics
-      if ((int)threadIdx.x < (P - 2) * (P - 2)) continue;
-#endif
       if ((code & ~(uint32_t)SFEM_IDX_MASK) == SFEM_IDX_SHARED) {
-#if SFEM_FACET_TIMING == 3 || SFEM_FACET_TIMING == 6     // timing only
-        asm volatile("" :: "v"(vals[w]), "v"(code));
-#elif SFEM_FACET_TIMING == 1
-        *facet_node<T, OFF32>(og, code) = vals[w];
-#else
         unsafeAtomicAdd(facet_node<T, OFF32>(og, code), vals[w]);
-#endif
       }
+    }
+  }
+}
+
+// Layered assembly: every class of the lane that is written goes out as plain
+// stores from the lane's own slots -- no LDS round trip, no atomics.
+template <typename T, int P, bool OFF32>
+__device__ __forceinline__ void facet_store_layered(
+    const FacetLane<P, true>& fl, const T (&acc)[P], T* og, bool lane_ok) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (lane_ok && !(fl.to[c] & FACET_SKIP)) {
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+        if (FacetLane<P, true>::cls(a) == c)
+          *facet_node<T, OFF32>(og, fl.ocode(a)) = acc[a];
+    }
+  }
+}
+
+// The same with the element's surface in SLOT order: face, edge and vertex
+// results change lanes through LDS (as for the atomics above), so that one
+// store instruction covers whole contiguous facet blocks; the element interior
+// leaves from the lanes' own slots.  Which order is faster depends on what else
+// the kernel keeps busy (config 2, timing builds with plain stores in place of
+// the atomics: box 0.494 ms in slot order / 0.574 own order, stored factors
+// 1.753 / 1.793, multilinear 0.820 / 0.766, p = 11 fp32 1.433 / 1.249):
+// ELEM::LAYERED_SLOTS.
+template <typename T, int P, bool OFF32>
+__device__ __forceinline__ void facet_store_layered_slots(
+    const FacetLane<P, true>& fl, const uint16_t (&slots)[6], const T (&acc)[P],
+    T* og, T* vals, uint32_t* codes, uint32_t own_w, bool lane_ok,
+    bool inner_lane) {
+  using L = FacetLayout<P>;
+  if (lane_ok && inner_lane) {
+#pragma unroll
+    for (int a = 1; a < P - 1; ++a)
+      *facet_node<T, OFF32>(og, fl.ocode(a)) = acc[a];
+  }
+  if (lane_ok) {
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+      vals[own_w + a * L::A] = acc[a];
+      codes[own_w + a * L::A] = fl.ocode(a);
+    }
+  }
+  facet_sync<P>();
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const uint32_t w = slots[q];
+    if (w != 0xFFFFu) {
+      const uint32_t code = codes[w];
+      if (!(code & FACET_SKIP)) *facet_node<T, OFF32>(og, code) = vals[w];
     }
   }
 }
@@ -391,12 +461,6 @@ __device__ __forceinline__ const char* kernarg_bytes() {
 #endif
 }
 
-#ifndef SFEM_FACET_TIMING
-#define SFEM_FACET_TIMING 0
-#endif
-#ifndef SFEM_FACET_XCD
-#define SFEM_FACET_XCD 0
-#endif
 #ifndef SFEM_FACET_AFFINE_MINW
 #define SFEM_FACET_AFFINE_MINW 5
 #endif
@@ -502,6 +566,8 @@ struct FacetElem {
                                     : SFEM_FACET_CHAIN_MINW_GEN);
   // chain launches are compiled where they pay (operators.py: box / affine)
   static constexpr bool CHAINS = GM == GEO_AFFINE || P <= 8;
+  // layered assembly: surface results in slot order (facet_store_layered_slots)
+  static constexpr bool LAYERED_SLOTS = P <= 8 && GM != GEO_MULTILINEAR;
   struct Raw { T c[GM == GEO_AFFINE ? 7 : 1]; int64_t e; };
   T cst[GM == GEO_AFFINE ? 6 : 1];
   T lw, Wm0;
@@ -706,6 +772,7 @@ struct BoxElem {
   static constexpr int CHAIN_MINW =
       P >= 9 ? SFEM_FACET_CHAIN_MINW_HI : SFEM_FACET_CHAIN_MINW_BOX;
   static constexpr bool CHAINS = true;
+  static constexpr bool LAYERED_SLOTS = P <= 8;
   struct Raw { T c[4]; };
   T P0, P1, P2, Wm;
 
@@ -792,12 +859,14 @@ struct BoxElem {
 };
 
 // One element per one-wave workgroup.  ELEM = FacetElem<..> / BoxElem<..>.
-template <typename T, int P, typename ELEM, bool SCALAR, bool OFF32>
+template <typename T, int P, typename ELEM, bool SCALAR, bool OFF32,
+          bool LAY = false>
 __global__ void __launch_bounds__(FacetLayout<P>::BLOCK, ELEM::MINW)
 helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   using L = FacetLayout<P>;
   using Mat = typename ELEM::Mat;
   using KA = FacetKernarg<FacetParams<T>, Mat>;
+  static_assert(!LAY || SCALAR, "layered assembly takes scalar fields");
   __shared__ T lds[ELEM::LDS_WORDS];
   T* s0 = lds;
   uint32_t* codes = reinterpret_cast<uint32_t*>(lds + L::COPY);
@@ -809,7 +878,7 @@ helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
                                   : (int64_t)work;
   const Mat* kdm = reinterpret_cast<const Mat*>(kernarg_bytes() + KA::MAT_OFF);
 
-  FacetLane<P> fl;
+  FacetLane<P, LAY> fl;
   fl.load(prm.tab, e, w.i, w.j);
   ELEM el;
   {
@@ -827,25 +896,30 @@ helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
     if (w.ok) {
 #pragma unroll
       for (int a = 0; a < P; ++a) {
-#if SFEM_FACET_TIMING == 4 || SFEM_FACET_TIMING == 6
-        ua[a] = (T)fl.code(a);
-#else
         ua[a] = *facet_node<const T, OFF32>(ug, fl.code(a));
-#endif
       }
     } else {
 #pragma unroll
       for (int a = 0; a < P; ++a) ua[a] = T(0);
     }
     el.apply(prm, dm, w, lds, ua, acc);
-    uint16_t slots[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) slots[q] = g_facet_slots<P>.s[w.lane][q];
     if (w.ok)
-      facet_scatter_head<T, P>(fl, acc, ua, prm.dot_out != nullptr, udot);
-    facet_scatter_tail<T, P, OFF32>(fl, slots, acc, og, s0, codes, w.own_w,
-                                    w.ok);
-    facet_sync<P>();
+      facet_scatter_head<T, P, LAY>(fl, acc, ua, prm.dot_out != nullptr, udot);
+    if constexpr (LAY && !ELEM::LAYERED_SLOTS) {
+      facet_store_layered<T, P, OFF32>(fl, acc, og, w.ok);
+    } else {
+      uint16_t slots[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) slots[q] = g_facet_slots<P>.s[w.lane][q];
+      if constexpr (LAY)
+        facet_store_layered_slots<T, P, OFF32>(
+            fl, slots, acc, og, s0, codes, w.own_w, w.ok,
+            FacetLane<P>::cls(w.i) == 1 && FacetLane<P>::cls(w.j) == 1);
+      else
+        facet_scatter_tail<T, P, OFF32>(fl, slots, acc, og, s0, codes, w.own_w,
+                                        w.ok);
+      facet_sync<P>();
+    }
   }
   if (prm.dot_out) {
 #pragma unroll
@@ -870,35 +944,34 @@ helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
 //     element's work instead of adding up.  (Gathering a whole element ahead
 //     -- 34 more live registers -- measured 0.569 vs 0.580 ms at 3 waves per
 //     SIMD and 0.655 with spills at 4: not kept.)
-template <typename T, int P, typename ELEM, bool OFF32>
+//   * layered assembly (LAY): the element that hands its face on does not
+//     write it (FACET_SKIP), the receiver stores the sum into ITS layer of the
+//     face's facets; everything leaves as plain stores from the lanes' own
+//     slots (no LDS round trip, no slot table).
+template <typename T, int P, typename ELEM, bool OFF32, bool LAY = false>
 __global__ void __launch_bounds__(FacetLayout<P>::BLOCK, ELEM::CHAIN_MINW)
 helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   using L = FacetLayout<P>;
   using Mat = typename ELEM::Mat;
   using KA = FacetKernarg<FacetParams<T>, Mat>;
+  using FL = FacetLane<P, LAY>;
   __shared__ T lds[ELEM::LDS_WORDS];
   T* s0 = lds;
   uint32_t* codes = reinterpret_cast<uint32_t*>(lds + L::COPY);
 
   FacetWave<P> w;
   w.init();
-#if SFEM_FACET_XCD
-  // blocks b, b + 8, ... share an XCD (and its L2): give each XCD a
-  // contiguous run of the segment list
-  const uint32_t nseg = gridDim.x, chunk = nseg >> 3, rem = nseg & 7;
-  const uint32_t xcd = blockIdx.x & 7;
-  const uint32_t seg = xcd * chunk + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-#else
   const uint32_t seg = blockIdx.x;
-#endif
   const int32_t k0 = prm.chain_off[seg];
   const int32_t k1 = prm.chain_off[seg + 1];
   const Mat* kdm = reinterpret_cast<const Mat*>(kernarg_bytes() + KA::MAT_OFF);
-  uint16_t slots[6];
+  constexpr bool OWN_ORDER = LAY && !ELEM::LAYERED_SLOTS;
+  uint16_t slots[OWN_ORDER ? 1 : 6];
+  if constexpr (!OWN_ORDER) {
 #pragma unroll
-  for (int q = 0; q < 6; ++q) slots[q] = g_facet_slots<P>.s[w.lane][q];
-  const bool face_inner = FacetLane<P>::cls(w.i) == 1 &&
-                          FacetLane<P>::cls(w.j) == 1;
+    for (int q = 0; q < 6; ++q) slots[q] = g_facet_slots<P>.s[w.lane][q];
+  }
+  const bool face_inner = FL::cls(w.i) == 1 && FL::cls(w.j) == 1;
   const T* ug = prm.u;
   T* og = prm.out;
 
@@ -906,8 +979,8 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   double udot = 0.0;
   T carry = T(0);
   {
-  FacetLane<P> fl, fn;
-  typename FacetLane<P>::Raw traw;
+  FL fl, fn;
+  typename FL::Raw traw;
   typename ELEM::Raw graw;
   fl.load(prm.tab, (int64_t)prm.chain_elems[k0], w.i, w.j);
   fn = fl;
@@ -917,8 +990,7 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   for (int a = 0; a < P; ++a)
     ua[a] = w.ok ? *facet_node<const T, OFF32>(ug, fl.code(a)) : T(0);
   if (k0 + 1 < k1)
-    FacetLane<P>::issue(traw, prm.tab, (int64_t)prm.chain_elems[k0 + 1], w.i,
-                        w.j);
+    FL::issue(traw, prm.tab, (int64_t)prm.chain_elems[k0 + 1], w.i, w.j);
   for (int32_t k = k0; k < k1; ++k) {
     const bool has_pred = k > k0, has_succ = k + 1 < k1;
     ELEM el;
@@ -933,12 +1005,16 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
     carry = acc[P - 1];
     // flags of this visit: the carried-in face interior is complete, the
     // carried-out face is left to the successor
-    FacetLane<P> fe = fl;
-    if (has_pred && face_inner) fe.t[0] &= ~(uint32_t)SFEM_IDX_SHARED;
-    if (has_succ) fe.t[2] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
+    FL fe = fl;
+    if constexpr (LAY) {
+      if (has_succ) fe.to[2] |= FACET_SKIP | SFEM_IDX_DIRICHLET;
+    } else {
+      if (has_pred && face_inner) fe.t[0] &= ~(uint32_t)SFEM_IDX_SHARED;
+      if (has_succ) fe.t[2] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
+    }
     const T u_last = ua[P - 1];
     if (w.ok)
-      facet_scatter_head<T, P>(fe, acc, ua, prm.dot_out != nullptr, udot);
+      facet_scatter_head<T, P, LAY>(fe, acc, ua, prm.dot_out != nullptr, udot);
     // next element: gather now, its successor's table with it
     fl = fn;
     if (has_succ) {
@@ -947,12 +1023,19 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
       for (int a = 1; a < P; ++a)
         ua[a] = w.ok ? *facet_node<const T, OFF32>(ug, fl.code(a)) : T(0);
       if (k + 2 < k1)
-        FacetLane<P>::issue(traw, prm.tab, (int64_t)prm.chain_elems[k + 2],
-                            w.i, w.j);
+        FL::issue(traw, prm.tab, (int64_t)prm.chain_elems[k + 2], w.i, w.j);
     }
-    facet_scatter_tail<T, P, OFF32>(fe, slots, acc, og, s0, codes, w.own_w,
-                                    w.ok);
-    facet_sync<P>();
+    if constexpr (OWN_ORDER) {
+      facet_store_layered<T, P, OFF32>(fe, acc, og, w.ok);
+    } else {
+      if constexpr (LAY)
+        facet_store_layered_slots<T, P, OFF32>(fe, slots, acc, og, s0, codes,
+                                               w.own_w, w.ok, face_inner);
+      else
+        facet_scatter_tail<T, P, OFF32>(fe, slots, acc, og, s0, codes, w.own_w,
+                                        w.ok);
+      facet_sync<P>();
+    }
   }
   }
   if (prm.dot_out) {
@@ -970,6 +1053,35 @@ template <typename T, int P, typename ELEM>
 int launch_facet_elem(const FacetParams<T>& prm, const typename ELEM::Mat& mat,
                       unsigned groups, bool off32, hipStream_t stream) {
   const dim3 grid(groups), block(FacetLayout<P>::BLOCK);
+  if (prm.layered) {
+    if (prm.ncomp != 1) {
+      set_error("helmholtz (facet): layered assembly takes scalar fields");
+      return SFEM_EINVAL;
+    }
+    if (prm.chain_off) {
+      if constexpr (ELEM::CHAINS) {
+        if (off32)
+          hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, true, true>),
+                             grid, block, 0, stream, prm, mat);
+        else
+          hipLaunchKernelGGL((helmholtz_chain_kernel<T, P, ELEM, false, true>),
+                             grid, block, 0, stream, prm, mat);
+      } else {
+        set_error("helmholtz (facet): no chain kernel for this geometry at "
+                  "P=%d", P);
+        return SFEM_EUNSUPPORTED;
+      }
+    } else if (off32) {
+      hipLaunchKernelGGL(
+          (helmholtz_facet_kernel<T, P, ELEM, true, true, true>), grid, block,
+          0, stream, prm, mat);
+    } else {
+      hipLaunchKernelGGL(
+          (helmholtz_facet_kernel<T, P, ELEM, true, false, true>), grid, block,
+          0, stream, prm, mat);
+    }
+    return SFEM_OK;
+  }
   if (prm.chain_off) {
     if constexpr (ELEM::CHAINS) {
       if (off32)

@@ -508,21 +508,6 @@ stokes_grad_t_box_kernel(StokesFacetParams<T> fprm, DMat<T, P> dm,
     FacetLane<P> fe = fl;
     if (has_pred && face_inner) fe.t[0] &= ~(uint32_t)SFEM_IDX_SHARED;
     if (has_succ) fe.t[2] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
-#if defined(SFEM_STOKES_TIMING)   // timing only: traffic of 2 x 2 bundles
-    {
-      const int pi = ((int)e >> 6) & 1, pj = (int)e & 1;
-      const bool don = (pi == 0 && w.i == P - 1) || (pj == 0 && w.j == P - 1);
-      const bool out_i = pi == 0 ? w.i == 0 : w.i == P - 1;
-      const bool out_j = pj == 0 ? w.j == 0 : w.j == P - 1;
-      const bool com = ((pi == 1 && w.i == 0) && !out_j) ||
-                       ((pj == 1 && w.j == 0) && !out_i);
-      if (don || (com && SFEM_STOKES_TIMING == 10)) {
-        if (don || has_pred) fe.t[0] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
-        fe.t[1] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
-        if (don) fe.t[2] |= SFEM_IDX_SHARED | SFEM_IDX_DIRICHLET;
-      }
-    }
-#endif
     {   // quadrature weight of the node
       const SFEM_CONSTANT_AS DMat<T, P>* km = StokesKernarg<T, P>::dm();
 #pragma unroll

@@ -31,6 +31,7 @@ import os
 
 import torch
 
+from swirl_fem_amd import switches
 from swirl_fem_amd import _lib
 from swirl_fem_amd import _ops
 from swirl_fem_amd.core import layout
@@ -158,7 +159,7 @@ class CGRunner:
     probe = getattr(M, 'mean_projection', None)
     if (probe is not None and dot_fn is None and reduce_fn is None and
         interface is None and isinstance(self.r, torch.Tensor) and
-        os.environ.get('SFEM_FUSED_MEAN', '1') != '0'):
+        switches.get('SFEM_FUSED_MEAN') != '0'):
       found = probe()
       if found is not None:
         w, total = found
@@ -166,6 +167,15 @@ class CGRunner:
                      float(total),
                      torch.zeros(_lib.SFEM_CG_MEAN_SUMS, dtype=torch.float64,
                                  device=device))
+    # Layered assembly: the operator leaves the contributions of shared nodes
+    # in layers of an extended Ap (plain stores: no atomics, no cleared range)
+    # and `r -= alpha Ap` adds them up where it streams Ap anyway, in a fixed
+    # order -- same sums, bitwise reproducible.  One partition, scalar field.
+    self.layered = None
+    if (self.fused_dot and self.mean is None and reduce_fn is None and
+        interface is None and self.p.dim() == 1 and
+        hasattr(A, 'apply_layered_with_dot')):
+      self.layered = A.layer_plan()
     self.issued = 0
     self._graph = None
 
@@ -223,7 +233,9 @@ class CGRunner:
     args = (self.maxiter, self.tol, self.atol, self.parts)
     merged = self.fused_dot and reduce_fn is None
     if self.fused_dot:
-      Ap = A.apply_with_dot(self.p, s.partials)
+      Ap = (A.apply_layered_with_dot(self.p, s.partials)
+            if self.layered is not None
+            else A.apply_with_dot(self.p, s.partials))
       # Without an all-reduce between the sum of the partials and alpha the
       # iteration needs ONE scalar launch: phase 5 also closes the previous
       # iteration (beta, gamma, counter, convergence flag) -- see `_flush`.
@@ -257,9 +269,13 @@ class CGRunner:
         _ops.cg_scalars(s.t, 1, *args)
       self.issued += 1
       return
-    for rr, aa in zip(_leaves(self.r), _leaves(Ap)):
-      _ops.cg_update_r(layout.flat(rr), layout.flat(layout.like(aa, rr)), s.t,
-                       self.fuse_rr)
+    if self.layered is not None:
+      _ops.cg_update_r_layered(self.r, Ap, self.layered.layers, s.t,
+                               self.fuse_rr)
+    else:
+      for rr, aa in zip(_leaves(self.r), _leaves(Ap)):
+        _ops.cg_update_r(layout.flat(rr), layout.flat(layout.like(aa, rr)),
+                         s.t, self.fuse_rr)
     if self.fuse_rr:
       z = self.r
       if self.fold_rr:

@@ -32,6 +32,7 @@ from typing import Any
 import numpy as np
 import torch
 
+from swirl_fem_amd import switches
 from swirl_fem_amd.core import autodiff
 from swirl_fem_amd.core import basis
 from swirl_fem_amd.core import layout
@@ -107,7 +108,7 @@ def _solve(differentiable, A, b, **kwargs):
 
 def _FUSED_DOTS():
   # SFEM_FUSED_DOTS=0: the pressure CG computes its inner products itself
-  return os.environ.get('SFEM_FUSED_DOTS', '1') != '0'
+  return switches.get('SFEM_FUSED_DOTS') != '0'
 
 
 class _PressureOperator:
@@ -116,7 +117,7 @@ class _PressureOperator:
   def __init__(self, sem, dt, time_order):
     self.sem, self.dt, self.time_order = sem, dt, time_order
     if (sem._divgrad() is not None and _FUSED_DOTS() and
-        os.environ.get('SFEM_SPLIT_E', '0') != '1'):
+        switches.get('SFEM_SPLIT_E') != '1'):
       self.apply_with_dot = self._apply_with_dot
 
   def __call__(self, p):
@@ -612,7 +613,7 @@ class StokesSEM:
                             else layout.component_major(q))
       # component-major intermediate: the shared-node atomics of one component
       # then hit whole lines (D^T 1.3 ms instead of 2.2 ms at 48^3, p = 7)
-      if op.penc is None and os.environ.get('SFEM_SPLIT_E', '0') == '1':
+      if op.penc is None and switches.get('SFEM_SPLIT_E') == '1':
         # opt-in: nodes held by one element stay in registers between D^T and
         # D.  4 % faster than the two kernels below while their atomics ran in
         # slot order; with the sorted shared scatter D^T alone dropped by a
@@ -671,7 +672,7 @@ class StokesSEM:
     # single-partition solves replay each CG iteration as one HIP graph launch
     # (iterations on small meshes are launch-bound); SFEM_GRAPHS=0 disables it
     graph = (self.velocity.mesh.axis_name is None and
-             os.environ.get('SFEM_GRAPHS', '1') != '0')
+             switches.get('SFEM_GRAPHS') != '0')
     # differentiable step (reference: lax.custom_linear_solve(symmetric=True),
     # :436-452): the cotangent of a solve is one more solve
     diff = autodiff.needs_grad(f, u_boundary, *us, *ps)
@@ -682,7 +683,7 @@ class StokesSEM:
     # the two solves of a step use the same operators step after step: their
     # recorded iterations are kept (SFEM_GRAPH_REUSE=0: record every solve)
     if (graph and not diff and self._reduce_fn() is None and
-        os.environ.get('SFEM_GRAPH_REUSE', '1') != '0'):
+        switches.get('SFEM_GRAPH_REUSE') != '0'):
       ws = self._cache.setdefault('cg_workspaces', {})
       keep = lambda *key: dict(workspace=ws, key=key + (tol, atol))
     else:
@@ -692,7 +693,7 @@ class StokesSEM:
     # p = 7: 2.14 against 2.20 s per step eager on one box, equal within the
     # noise on another -- and the eager loop does not hold a second set of
     # solver vectors)
-    limit = int(os.environ.get('SFEM_GRAPH_MAX_NUMEL', str(1 << 25)))
+    limit = int(switches.get('SFEM_GRAPH_MAX_NUMEL'))
     small = lambda b: graph and b.numel() <= limit
     u_star, info = _solve(diff, H_, f, M=self.velocity.exchange, tol=tol,
                           atol=atol, graph=small(f),

@@ -17,6 +17,8 @@ import ctypes.util
 import glob
 import os
 
+from swirl_fem_amd import switches
+
 import numpy as np
 
 _H5F_ACC_RDONLY, _H5F_ACC_TRUNC = 0, 2
@@ -33,7 +35,7 @@ class H5Error(RuntimeError):
 
 
 def _candidates():
-  env = os.environ.get('SFEM_HDF5_LIB')
+  env = switches.get('SFEM_HDF5_LIB')
   if env:
     yield env
   found = ctypes.util.find_library('hdf5')

@@ -45,3 +45,18 @@ class F32Rng:
 
   def __getattr__(self, name):       # permutation, integers, choice, ...
     return getattr(self._rng, name)
+
+
+def tolerance(dtype, P):
+  """Relative tolerance of a fused kernel against the fp64 oracle: north_star's
+  1e-10 (fp64) / 1e-5 (fp32).  One documented exception, P >= 11 in fp32: 2e-5.
+  There the REFERENCE ALGORITHM evaluated in float32 is itself 1.0e-5..1.8e-5
+  from the fp64 oracle (profiles/r04_fp32_errors.md, rows `helmholtz | 2 | 12`,
+  `helmholtz | 3 | 12`, `stokes | 3 | 12`), the kernels 0.3e-5..1.0e-5 on most
+  meshes and 1.8e-5 on one (2D, jittered, stored factors) -- a 12-point
+  derivative matrix has entries of 1e2 and sums 12 products per line, 36 per
+  point, in single precision."""
+  import torch
+  if dtype == torch.float64:
+    return 1e-10
+  return 1e-5 if P <= 10 else 2e-5

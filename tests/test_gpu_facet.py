@@ -19,7 +19,7 @@ from swirl_fem_amd.core.fespace import FiniteElementSpace
 from swirl_fem_amd.core.interpolation import Nodes1D, NodeType, Quadrature1D
 from swirl_fem_amd.core import operators
 from swirl_fem_amd.core.mesh_refiner import refine_premesh
-from tests.fp32util import F32Rng, f32_mesh
+from tests.fp32util import F32Rng, f32_mesh, tolerance
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -140,7 +140,7 @@ def test_facet_helmholtz_matches_oracle(P, dtype, chain, monkeypatch):
   """`chain`: scalar fields walk chains of elements (segments of <= 16 / 3
   elements, the shared face carried in registers) or one element per wave
   (P <= 8) / workgroup (P >= 9)."""
-  tol = TOL[dtype]
+  tol = tolerance(dtype, P)
   if chain == 'off':
     monkeypatch.setenv('SFEM_CHAIN', '0')
     monkeypatch.setenv('SFEM_CHAIN_LEN', '8')    # built, not used
@@ -279,7 +279,8 @@ def test_facet_kernels_with_64_bit_addressing(P, monkeypatch):
         uu = u[:, 0] if nc == 1 else u
         ud = dev(uu, dtype) if nc == 1 else dev(u.T.copy(), dtype).t()
         got = op.apply(ud, 0.4, 1.2)
-        assert relerr(got, reference(ofes, uu, 0.4, 1.2, mk)) < TOL[dtype]
+        assert relerr(got, reference(ofes, uu, 0.4, 1.2, mk)) < tolerance(
+            dtype, P)
 
 
 def test_chain_segments_follow_the_mesh_size(monkeypatch):
@@ -413,6 +414,7 @@ def test_headline_chain_instantiation_matches_oracle(chain_len, dtype,
     ofes = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'), (P, 'gll'))
     bmask = mesh.physical_masks['boundary']
     mk = bmask.cpu().numpy()
+    o32 = None
     for mask_t, mask_np in ((bmask, mk), (None, None)):
       op = fes.helmholtz_operator(mask_t)
       assert len(op.facet_parts) == 1
@@ -434,14 +436,29 @@ def test_headline_chain_instantiation_matches_oracle(chain_len, dtype,
         for l0, l1 in ((0.0, 1.0), (0.6, 1.4)):
           ref = reference(ofes, uu, l0, l1, mask_np)
           got = op.apply(ud, l0, l1)
-          assert relerr(got, ref) < tol, (mode, nc, l0, l1, mask_t is None)
+          bar = tol
+          if dtype == torch.float32 and mode == 'sheared':
+            # elements of aspect ratio 4, sheared: the REFERENCE ALGORITHM in
+            # float32 is 1.2e-5 .. 2.7e-5 from the fp64 oracle on this mesh
+            # (profiles/r04_fp32_errors.md, `sheared 8x2x2`: the kernel's
+            # error is 0.6 .. 1.05 of it); the bar is 1e-5 or 1.5 x that
+            # reference error, whichever is larger
+            if o32 is None:
+              o32 = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'),
+                              (P, 'gll'), dtype=np.float32)
+            bar = max(tol, 1.5 * relerr(torch.as_tensor(reference(
+                o32, uu.astype(np.float32), np.float32(l0), np.float32(l1),
+                mask_np)), ref))
+          assert relerr(got, ref) < bar, (mode, nc, l0, l1, mask_t is None)
+          if (l0, l1) == (0.0, 1.0):
+            bar_stiffness = bar
         ref = reference(ofes, uu, 0.0, 1.0, mask_np)
         want = float((uu * ref).sum())
         scale = float(np.abs(uu * ref).sum())
         parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
                             device=DEV)
         got = op.apply(ud, 0.0, 1.0, dot_out=parts)
-        assert relerr(got, ref) < tol, (mode, nc, 'dot')
+        assert relerr(got, ref) < bar_stiffness, (mode, nc, 'dot')
         assert abs(float(parts.sum()) - want) <= 10 * tol * scale, (mode, nc)
 
 
@@ -483,3 +500,143 @@ def test_chain_launch_without_an_instantiation_is_an_error(monkeypatch):
   u = dev(rng.standard_normal(mesh.num_nodes))
   assert relerr(opc.apply(u), ref.apply(u).cpu().numpy()) < 1e-12
   del good
+
+
+@pytest.mark.parametrize('P,chain', [(6, '3'), (7, '16'), (8, '3'), (8, '16'),
+                                     (8, 'off'), (9, 'off'), (12, 'off')])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_layered_assembly_matches_oracle(P, chain, dtype, monkeypatch):
+  """Layered assembly (`build_layer_plan`, `apply_layered`, `fold_layers`):
+  every (element, facet) writes its contribution to a layer of its own with a
+  plain store, the layers are added up afterwards -- the direct-stiffness sum
+  of core/gather_scatter.py:130-133 without atomics.  Against the oracle and
+  against the atomic assembly of the same operator, on every geometry kind,
+  with chains (carried faces are written by the receiver only) and without,
+  rotated elements, Dirichlet rows, fused u . A u; and bitwise reproducible."""
+  tol = tolerance(dtype, P)
+  if chain == 'off':
+    monkeypatch.setenv('SFEM_CHAIN', '0')
+  else:
+    monkeypatch.setenv('SFEM_CHAIN_LEN', chain)
+  modes = (('structured', False), ('stretched', True), ('sheared', True),
+           ('jittered', True))
+  if P >= 9:
+    modes = (('structured', False), ('sheared', True))
+  for mode, rotate in modes:
+    rng = F32Rng(7 * P + len(mode))
+    n = 3 if P <= 7 else 2
+    rp = f32_mesh(make_mesh(n, P, mode, rng, rotate), dtype)
+    mesh = rp.finalize(device=DEV, dtype=dtype)
+    fes = FiniteElementSpace.create(
+        mesh, Quadrature1D.create_from_nodes_1d(Nodes1D.create(P, GLL)))
+    ofes = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'), (P, 'gll'))
+    bmask = mesh.physical_masks['boundary']
+    N = mesh.num_nodes
+    for geometry in ('auto', 'stored'):
+      for mask_t in (bmask, None):
+        op = operators.HelmholtzOperator.create(fes, mask_t, geometry)
+        plan = op.layer_plan()
+        assert plan is not None, (mode, geometry)
+        assert plan.extent >= N and len(plan.layers) >= 1
+        # interior vertices of an n^3 mesh have 8 holders (4 writers when
+        # the chains carry one direction)
+        assert len(plan.layers) + 1 >= (4 if chain != 'off' and P <= 8 else 8) \
+            or n < 3
+        lens = [l for l, _ in plan.layers]
+        assert lens == sorted(lens, reverse=True) and lens[0] <= N + 3
+        if P <= 8 and chain != 'off':
+          assert 'helmholtz_chain_kernel' in op.kernel_name(layered=True)
+        assert op.kernel_name(layered=True).endswith('*, true>')
+        mk = None if mask_t is None else mask_t.cpu().numpy()
+        u = rng.standard_normal(N)
+        ud = dev(u, dtype)
+        for l0, l1 in ((0.0, 1.0), (0.6, 1.4), (1.0, 0.0)):
+          ref = reference(ofes, u, l0, l1, mk)
+          ext = op.new_extended()
+          parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64,
+                              device=DEV)
+          op.apply_layered(ud, ext, l0, l1, dot_out=parts)
+          raw = ext.clone()
+          got = _ops.fold_layers(ext, N, plan.layers)
+          assert relerr(got, ref) < tol, (mode, geometry, l0, l1)
+          atomic = op.apply(ud, l0, l1)
+          assert relerr(got, atomic.double().cpu().numpy()) < (
+              1e-13 if dtype == torch.float64 else 2e-6)
+          want = float((u * ref).sum())
+          scale = float(np.abs(u * ref).sum())
+          assert abs(float(parts.sum()) - want) <= 10 * tol * scale
+          # the same buffer again (slots nobody writes still zero), and a
+          # fresh one: bit for bit the same
+          op.apply_layered(ud, ext, l0, l1)
+          assert torch.equal(ext[N:], raw[N:])
+          again = _ops.fold_layers(ext, N, plan.layers).clone()
+          ext2 = op.new_extended()
+          op.apply_layered(ud, ext2, l0, l1)
+          assert torch.equal(ext2, raw)
+          assert torch.equal(again, _ops.fold_layers(ext2, N, plan.layers))
+    # a split operator covers part of the mesh: no plan; so does one whose
+    # elements partly keep their index rows
+    half = torch.arange(mesh.num_elements, device=DEV) % 2 == 0
+    a, b = op.split(half)
+    assert a.layer_plan() is None and b.layer_plan() is None
+    monkeypatch.setenv('SFEM_LAYERED', '0')
+    assert operators.HelmholtzOperator.create(fes, None).layer_plan() is None
+    monkeypatch.delenv('SFEM_LAYERED')
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_cg_with_layered_assembly(dtype, monkeypatch):
+  """`linalg.cg` adds the layers of Ap up inside `r -= alpha Ap`
+  (`sfem_cg_update_r_layered`): same iterates and iteration count as the
+  atomic assembly and as the oracle's CG (linalg/cg.py:54-97), bitwise equal
+  from run to run, also under graph replay and with a preconditioner slot."""
+  from swirl_fem_amd.linalg.cg import CGRunner, cg
+  P = 8
+  monkeypatch.setenv('SFEM_CHAIN_LEN', '3')
+  rng = F32Rng(11)
+  rp = f32_mesh(make_mesh(3, P, 'stretched', rng), dtype)
+  mesh = rp.finalize(device=DEV, dtype=dtype)
+  fes = FiniteElementSpace.create(
+      mesh, Quadrature1D.create_from_nodes_1d(Nodes1D.create(P, GLL)))
+  ofes = O.FESpace(rp.node_coords, rp.elements, (P, 'gll'), (P, 'gll'))
+  bmask = mesh.physical_masks['boundary']
+  mk = bmask.cpu().numpy()
+  op = operators.HelmholtzOperator.create(fes, bmask)
+  A = op.linear_operator(0.0, 1.0)
+  b = rng.standard_normal(mesh.num_nodes) * ~mk
+  bd = dev(b, dtype)
+  f64 = dtype == torch.float64
+  tol = 1e-10 if f64 else 1e-5
+
+  run = CGRunner(A, bd, tol=tol)
+  assert run.layered is not None and len(run.layered.layers) >= 3
+  monkeypatch.setenv('SFEM_LAYERED', '0')
+  op_a = operators.HelmholtzOperator.create(fes, bmask)
+  plain = CGRunner(op_a.linear_operator(0.0, 1.0), bd, tol=tol)
+  monkeypatch.delenv('SFEM_LAYERED')
+  assert plain.layered is None
+  for it in range(12):
+    run.step()
+    plain.step()
+    err = float((run.x - plain.x).abs().max() / plain.x.abs().max())
+    assert err < (1e-11 if f64 else 1e-4), (it, err)
+  # whole solves: oracle, atomic, layered (twice: bitwise), graph replay
+  xo, info_o = O.cg(lambda v: reference(ofes, v, 0.0, 1.0, mk), b, tol=tol)
+  x1, i1 = cg(A, bd, tol=tol)
+  x2, i2 = cg(A, bd, tol=tol)
+  xa, ia = cg(op_a.linear_operator(0.0, 1.0), bd, tol=tol)
+  xg, ig = cg(A, bd, tol=tol, graph=True)
+  assert torch.equal(x1, x2) and i1['num_iterations'] == i2['num_iterations']
+  assert torch.equal(x1, xg) and ig['num_iterations'] == i1['num_iterations']
+  slack = 0 if f64 else 3
+  assert abs(i1['num_iterations'] - info_o['num_iterations']) <= slack
+  assert abs(i1['num_iterations'] - ia['num_iterations']) <= slack
+  assert relerr(x1, xo) < (1e-8 if f64 else 2e-3)
+  assert relerr(x1, xa.double().cpu().numpy()) < (1e-9 if f64 else 2e-3)
+  # a preconditioner in the M slot (Jacobi): the update runs with fuse_rr = 0
+  diag = op.apply(torch.ones_like(bd), 1.0, 0.0) + bmask.to(bd.dtype)
+  M = lambda r: r / diag
+  xm, im = cg(A, bd, tol=tol, M=M)
+  xm_a, im_a = cg(op_a.linear_operator(0.0, 1.0), bd, tol=tol, M=M)
+  assert abs(im['num_iterations'] - im_a['num_iterations']) <= slack
+  assert relerr(xm, xm_a.double().cpu().numpy()) < (1e-9 if f64 else 2e-3)

@@ -14,7 +14,7 @@ from swirl_fem_amd.core.fespace import FiniteElementSpace
 from swirl_fem_amd.core.interpolation import (Nodes1D, NodeType, Quadrature1D)
 from swirl_fem_amd.core.mesh_refiner import refine_premesh
 from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
-from tests.fp32util import F32Rng, f32_mesh
+from tests.fp32util import F32Rng, f32_mesh, tolerance
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -83,7 +83,7 @@ def test_div_and_grad_t_match_oracle(ndim, n, P, dtype, monkeypatch):
   # through its chain kernels as well where they exist)
   if ndim == 3 and P == 8:
     monkeypatch.setenv('SFEM_STOKES_FACET_DIV', 'all')
-  tol = 1e-10 if dtype == torch.float64 else 1e-5
+  tol = tolerance(dtype, P)
   for shear, jitter in ((True, 0.0), (False, 0.15)):   # affine, multilinear
     rng, vsp, psp, ov, op = build(ndim, n, P, dtype, jitter=jitter,
                                   shear=shear)
@@ -142,7 +142,7 @@ def test_split_pressure_operator_matches_oracle(ndim, n, P, dtype):
   """E = D Q D^T in two halves (`sfem_stokes_e_first` / `_second`: nodes held
   by one element stay in registers) against the oracle's composition of
   navier_stokes.py:313-348 and against the two-kernel path."""
-  tol = 1e-10 if dtype == torch.float64 else 1e-4
+  tol = tolerance(dtype, P)
   for shear, jitter in ((True, 0.0), (False, 0.15)):
     rng, vsp, psp, ov, op = build(ndim, n, P, dtype, jitter=jitter,
                                   shear=shear)
@@ -408,7 +408,7 @@ def test_fused_convection_matches_oracle(ndim, n, P, extra, dtype):
   """C_local on the over-integration space (navier_stokes.py:183-188,
   :238-245): interpolate -> fused kernel on the quadrature grid -> transposed
   interpolation, vs the oracle's dense evaluation, incl. reflected elements."""
-  tol = 1e-10 if dtype == torch.float64 else 1e-5
+  tol = tolerance(dtype, P)
   rng = F32Rng(31)
   pm = unit_cube_mesh(n, ndim=ndim)
   pm = pm.replace(node_coords=pm.node_coords + 0.15 / n * rng.uniform(

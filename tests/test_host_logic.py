@@ -723,3 +723,48 @@ def test_facet_chains_contract():
                       dtype=torch.int32)
   off, elems = operators.facet_chains(ring, torch.arange(2), 2, 16)
   assert off.tolist() == [0, 1, 2] and sorted(elems.tolist()) == [0, 1]
+
+
+def test_every_environment_switch_is_registered_and_documented():
+  """`swirl_fem_amd/switches.py` is the one table of `SFEM_*` environment
+  switches: every name the product reads (Python `switches.get`, C `getenv`)
+  is in it, nothing reads the environment behind its back, INTEGRATION.md
+  lists them all, and unknown names are reported instead of ignored."""
+  import glob
+  import re
+  import warnings
+  from swirl_fem_amd import switches
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  used = set()
+  for path in glob.glob(os.path.join(root, 'swirl_fem_amd', '**', '*.py'),
+                        recursive=True) + [os.path.join(root, 'bench.py')]:
+    text = open(path).read()
+    if not path.endswith('switches.py'):
+      assert not re.search(r"os\.environ[^\n]*SFEM_", text), path
+    used |= set(re.findall(r"switches\.(?:get|enabled)\('(SFEM_[A-Z0-9_]+)'",
+                           text))
+  for path in glob.glob(os.path.join(root, 'swirl_fem_amd', 'csrc', '*.h*')):
+    used |= set(re.findall(r'getenv\("(SFEM_[A-Z0-9_]+)"\)', open(path).read()))
+  assert used, 'no switch found: the patterns of this test are stale'
+  assert used <= set(switches.SWITCHES), used - set(switches.SWITCHES)
+  doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+  for name in switches.SWITCHES:
+    assert '`%s`' % name in doc, name
+  with pytest.raises(KeyError):
+    switches.get('SFEM_NOT_A_SWITCH')
+  os.environ['SFEM_TYPO_IN_A_NAME'] = '1'
+  try:
+    switches._checked = False
+    with warnings.catch_warnings(record=True) as caught:
+      warnings.simplefilter('always')
+      assert switches.check_environment() == ['SFEM_TYPO_IN_A_NAME']
+    assert any('SFEM_TYPO_IN_A_NAME' in str(w.message) for w in caught)
+  finally:
+    del os.environ['SFEM_TYPO_IN_A_NAME']
+  os.environ['SFEM_BOX'] = '0'
+  try:
+    assert switches.active().get('SFEM_BOX') == '0'
+    assert not switches.enabled('SFEM_BOX')
+  finally:
+    del os.environ['SFEM_BOX']
+  assert switches.enabled('SFEM_BOX') and not switches.enabled('SFEM_MFMA')
