@@ -556,6 +556,28 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
                      int fuse_rr, int dtype, sfem_stream_t stream);
 int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
                       double* scalars, int dtype, sfem_stream_t stream);
+/* Lazy solution update: sfem_cg_update_xp with x touched every m-th iteration
+ * only.  `pring`: m direction vectors, slot s at pring + s * ring_stride
+ * (elements; ring_stride a multiple of 16 bytes); p_k lives in slot k mod m,
+ * k = scalars[8], and  p_{k+1} = z + beta p_k  goes to the next slot.  When
+ * (k + 1) mod m = 0 the pending terms are added,
+ *   x = (((x + alpha_{k-m+1} p_{k-m+1}) + ...) + alpha_k p_k),
+ * in the order and with the roundings of the iteration-by-iteration update
+ * (cg.py:80): bitwise the same x, (4 m + 1) / m vector passes per iteration
+ * instead of 5.  `lazy`: 1 + SFEM_CG_LAZY_MAX device doubles owned by the
+ * solve, zero before the first iteration ([0] = iterations already in x,
+ * [1 + s] = alpha of slot s).  sfem_cg_flush_x adds what is still pending
+ * after scalars[8] iterations (call it before reading x; the open iteration
+ * of the one-scalar-launch scheme must be closed first: sfem_cg_scalars
+ * phase 6).                                                                  */
+#define SFEM_CG_LAZY_MAX 8
+int sfem_cg_update_xp_lazy(void* x, void* pring, int64_t ring_stride,
+                           const void* z, int64_t count, double* scalars,
+                           double* lazy, int m, int dtype,
+                           sfem_stream_t stream);
+int sfem_cg_flush_x(void* x, const void* pring, int64_t ring_stride,
+                    int64_t count, const double* scalars, double* lazy, int m,
+                    int dtype, sfem_stream_t stream);
 /* Layered assembly (sfem_helmholtz_args.layered_extent): the operator result
  * is an EXTENDED vector  [ count nodal values | layer 1 | layer 2 | ... ];
  * layer k (k = 0 .. num_layers-1 here) holds further contributions to the

@@ -878,6 +878,27 @@ def cg_update_r(r, ap, scalars, fuse_rr):
         _dtype_code(r), _stream(dev)), 'sfem_cg_update_r')
 
 
+def cg_update_xp_lazy(x, pring, z, scalars, lazy):
+  """p_{k+1} = z + beta p_k into the next slot of the ring `pring` (m, stride);
+  x takes its m pending terms every m-th iteration (`sfem_cg_update_xp_lazy`)."""
+  dev = _dev(x, pring, z, scalars, lazy)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_xp_lazy(
+        _ptr(x), _ptr(pring), pring.stride(0), _ptr(z), x.numel(),
+        _ptr(scalars), _ptr(lazy), pring.shape[0], _dtype_code(x),
+        _stream(dev)), 'sfem_cg_update_xp_lazy')
+
+
+def cg_flush_x(x, pring, scalars, lazy):
+  """Adds the terms of x the lazy update still holds back."""
+  dev = _dev(x, pring, scalars, lazy)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_flush_x(
+        _ptr(x), _ptr(pring), pring.stride(0), x.numel(), _ptr(scalars),
+        _ptr(lazy), pring.shape[0], _dtype_code(x), _stream(dev)),
+        'sfem_cg_flush_x')
+
+
 def cg_update_xp(x, p, z, scalars):
   dev = _dev(x, p, z, scalars)
   with torch.cuda.device(dev):

@@ -46,6 +46,10 @@ SWITCHES = {
     'SFEM_LAYERED': ('1', 'core/operators.py',
                      '0: CG keeps the atomic assembly; force: layered '
                      'assembly also for elements with stored factors'),
+    'SFEM_LAZY_X': ('4', 'linalg/cg.py',
+                    'directions the CG keeps before it adds them to x '
+                    '(vectors of 256 MB and more; 0 or 1: x += alpha p every '
+                    'iteration)'),
     'SFEM_SORTED_SCATTER': ('1', 'core/operators.py',
                             '0: index-row kernels issue their atomics in slot '
                             'order instead of node order'),

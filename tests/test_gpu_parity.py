@@ -1423,3 +1423,71 @@ def test_config5_properties_at_scale(n):
   op.apply(u, 0.5, 1.0, dot_out=parts)
   ref = float(torch.dot(u.double(), Hu.double()))
   assert abs(float(parts.sum()) - ref) < 1e-5 * abs(ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('m', [4, 2, 3])
+def test_cg_lazy_solution_update_is_bitwise_the_same(dtype, m, monkeypatch):
+  """`sfem_cg_update_xp_lazy`: x takes its terms every m-th iteration only,
+  in the order and with the roundings of `x += alpha p` (linalg/cg.py:80) --
+  bit for bit the x of the iteration-by-iteration update after ANY number of
+  iterations (the pending terms are added when x is read), same iteration
+  count, also across `restart` and when somebody peeks at x mid-batch."""
+  from swirl_fem_amd.linalg import cg as cg_mod
+  rp = make_case(3, 3, 5, seed=3)
+  mesh, fes, _ = spaces(rp, 5, 5, 'gll', dtype)
+  bmask = mesh.physical_masks['boundary']
+  op = fes.helmholtz_operator(bmask)
+  A = op.linear_operator(0.3, 1.0)
+  g = torch.Generator(device=DEV).manual_seed(2)
+  b = torch.randn(mesh.num_nodes, dtype=dtype, device=DEV, generator=g) * ~bmask
+  monkeypatch.setenv('SFEM_LAZY_X', '0')
+  plain = cg_mod.CGRunner(A, b, tol=0.0, maxiter=10 ** 6)
+  assert plain.lazy is None and plain.vector_passes == 8
+  xs = []
+  for _ in range(11):
+    plain.step()
+    xs.append(plain.x.clone())
+  monkeypatch.setenv('SFEM_LAZY_X', str(m))
+  monkeypatch.setattr(cg_mod, 'LAZY_X_MIN_BYTES', 0)
+  for k in range(1, 12):          # k iterations, x read once at the end
+    run = cg_mod.CGRunner(A, b, tol=0.0, maxiter=10 ** 6)
+    assert run.lazy is not None and run.lazy[0].shape[0] == m
+    assert abs(run.vector_passes - (3 + (4 * m + 1) / m)) < 1e-12
+    for _ in range(k):
+      run.step()
+    assert torch.equal(run.x, xs[k - 1]), k
+    assert torch.equal(run.x, xs[k - 1])            # reading twice adds nothing
+  run = cg_mod.CGRunner(A, b, tol=0.0, maxiter=10 ** 6)
+  for k in range(11):             # peeking every iteration
+    run.step()
+    assert torch.equal(run.x, xs[k]), k
+    assert torch.equal(run.p, plain.p) or k < 10
+  # whole solves, and the state reused for a second right-hand side
+  tol = 1e-9 if dtype == torch.float64 else 1e-5
+  ws = {}
+  x1, i1 = cg_mod.cg(A, b, tol=tol)
+  monkeypatch.setenv('SFEM_LAZY_X', '0')
+  x0, i0 = cg_mod.cg(A, b, tol=tol)
+  assert torch.equal(x1, x0) and i1['num_iterations'] == i0['num_iterations']
+  assert i1['status'] == 'converged'
+  b2 = torch.randn(mesh.num_nodes, dtype=dtype, device=DEV, generator=g) * ~bmask
+  y0, j0 = cg_mod.cg(A, b2, tol=tol)
+  monkeypatch.setenv('SFEM_LAZY_X', str(m))
+  run = cg_mod.CGRunner(A, b, tol=tol)
+  while not run.done():
+    for _ in range(5):
+      run.step()
+  assert torch.equal(run.x, x0)
+  run.restart(b2)
+  while not run.done():
+    for _ in range(7):
+      run.step()
+  assert torch.equal(run.x, y0)
+  assert run.info()['num_iterations'] == j0['num_iterations']
+  # graph replay keeps fixed operands: the ring is dropped before recording
+  run = cg_mod.CGRunner(A, b, tol=tol)
+  assert run.lazy is not None and run.capture() and run.lazy is None
+  while not run.done():
+    run.step()
+  assert torch.equal(run.x, x0)
