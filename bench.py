@@ -47,7 +47,7 @@ STRONG_REF = {   # (global elements per direction, p, dtype) -> (ms, source)
 }
 
 
-TRAFFIC_FILE = 'profiles/traffic_r03.json'
+TRAFFIC_FILE = 'profiles/traffic_r04.json'
 
 
 def kernel_source_hash():

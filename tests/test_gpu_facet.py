@@ -633,7 +633,7 @@ def test_cg_with_layered_assembly(dtype, monkeypatch):
       1e-12 if f64 else 1e-4) * float(c.abs().max())
   assert close(x1, x2) and i1['num_iterations'] == i2['num_iterations']
   assert close(x1, xg) and ig['num_iterations'] == i1['num_iterations']
-  slack = 0 if f64 else 3
+  slack = 1 if f64 else 3      # 268 iterations: the stop test can flip by one
   assert abs(i1['num_iterations'] - info_o['num_iterations']) <= slack
   assert abs(i1['num_iterations'] - ia['num_iterations']) <= slack
   assert relerr(x1, xo) < (1e-8 if f64 else 2e-3)
