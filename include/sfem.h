@@ -313,6 +313,13 @@ typedef struct sfem_helmholtz_args {
   /* writes the sum).  Slots no element writes must hold zero; the kernel      */
   /* issues plain stores only and clears nothing (zero_begin/zero_end unused). */
   int64_t layered_extent;
+  /* with layered_extent and dot_out: 0 = dot_out is SFEM_DOT_SLOTS atomically  */
+  /* accumulated slots as above; > 0 = dot_out holds dot_slots doubles, at      */
+  /* least one per wave of the launch (workgroups x ceil(P^2 / 64)); wave w     */
+  /* STORES its partial sum of u . out at dot_out[w] -- nothing to clear, and   */
+  /* the sum over the slots in index order (sfem_cg_scalars_n) is bitwise       */
+  /* reproducible                                                               */
+  int64_t dot_slots;
 } sfem_helmholtz_args;
 
 /* Compact connectivity of refiner-numbered meshes (reference numbering:
@@ -556,6 +563,24 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
                      int fuse_rr, int dtype, sfem_stream_t stream);
 int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
                       double* scalars, int dtype, sfem_stream_t stream);
+/* Reproducible inner products.  sfem_cg_scalars_n = sfem_cg_scalars reading
+ * `num_partials` STORED partial sums of p.Ap (sfem_helmholtz_args.dot_slots;
+ * phases 3, 4, 5: summed in a fixed order, not cleared), plus phase 8:
+ * gamma_new (scalars[2]) <- the fixed-order sum of `num_partials` stored
+ * per-workgroup sums of r.r.  sfem_cg_update_r_layered with rr_partials != NULL
+ * (fuse_rr != 0) stores its workgroups' sums there instead of accumulating them
+ * atomically; `*num_rr` receives the number of workgroups (<= rr_capacity, the
+ * launch is sized to fit).  A CG iteration built from these and the layered
+ * apply is bitwise reproducible from run to run.                              */
+int sfem_cg_scalars_n(double* scalars, int phase, double maxiter, double tol,
+                      double atol, double* partials, int64_t num_partials,
+                      sfem_stream_t stream);
+int sfem_cg_update_r_layered_det(void* r, const void* ap_ext, int64_t count,
+                                 const int64_t* layer_len,
+                                 const int64_t* layer_off, int num_layers,
+                                 double* scalars, double* rr_partials,
+                                 int64_t rr_capacity, int64_t* num_rr,
+                                 int dtype, sfem_stream_t stream);
 /* Lazy solution update: sfem_cg_update_xp with x touched every m-th iteration
  * only.  `pring`: m direction vectors, slot s at pring + s * ring_stride
  * (elements; ring_stride a multiple of 16 bytes); p_k lives in slot k mod m,

@@ -47,7 +47,7 @@ class HelmholtzArgs(ctypes.Structure):
       ('cluster_nodes', c_ptr), ('num_clusters', c_i64),
       ('facet_table', c_ptr), ('geo_const', c_ptr),
       ('chain_offsets', c_ptr), ('chain_elems', c_ptr), ('num_chains', c_i64),
-      ('layered_extent', c_i64),
+      ('layered_extent', c_i64), ('dot_slots', c_i64),
   ]
 
 
@@ -124,6 +124,10 @@ SIGNATURES = {
     'sfem_cg_update_r_layered': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
                                  c_ptr, c_i32, c_i32, c_ptr],
     'sfem_fold_layers': [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
+    'sfem_cg_scalars_n': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr, c_i64,
+                          c_ptr],
+    'sfem_cg_update_r_layered_det': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
+                                     c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_cg_update_xp_lazy': [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr,
                                c_i32, c_i32, c_ptr],
     'sfem_cg_flush_x': [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32,

@@ -424,7 +424,7 @@ def _dptr(t):
 
 def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
                     lambda0, lambda1, zero_range, dot_out=None,
-                    layered_extent=0):
+                    layered_extent=0, dot_slots=0):
   """Builds `sfem_helmholtz_args`; `part` = dict(geo_mode, geo, geo_elem,
   geo_index, elem_list), `host` = dict(dmat, weights, nodes) NumPy arrays
   (kept alive by the caller for the duration of the call)."""
@@ -479,7 +479,7 @@ def _helmholtz_args(u, out, enc, part, host, ndim, P, num_elements, num_nodes,
       chain_offsets=_dptr(ch[0] if ch is not None else None),
       chain_elems=_dptr(ch[1] if ch is not None else None),
       num_chains=0 if ch is None else ch[0].numel() - 1,
-      layered_extent=int(layered_extent))
+      layered_extent=int(layered_extent), dot_slots=int(dot_slots))
 
 
 _CLUSTER_LIMITS = {}
@@ -560,23 +560,49 @@ def helmholtz_apply(u, out, enc, parts, host, ndim, P, lambda0, lambda1,
   return out
 
 
+def layered_dot_waves(parts, P, num_elements):
+  """Waves each launch of a layered apply starts (its share of a per-wave
+  `dot_out`): workgroups (chain segments or elements) x ceil(P^2 / 64)."""
+  waves = (P * P + 63) // 64
+  out = []
+  for part in parts:
+    if part.get('layered_chains'):
+      groups = part['chains'][0].numel() - 1
+    elif 'elem_list' in part:
+      groups = part['elem_list'].numel()
+    else:
+      groups = num_elements
+    out.append(groups * waves)
+  return out
+
+
 def helmholtz_apply_layered(u, ext, enc, parts, host, ndim, P, lambda0,
-                            lambda1, dot_out=None):
+                            lambda1, dot_out=None, per_wave=False):
   """`sfem_helmholtz_apply` with layered assembly: `ext` is the extended
   output [N nodal values | layers] of the operator's layer plan (slots nobody
   writes hold zero), `parts` carry `layered_table`.  Scalar fields; nothing is
-  cleared, no atomics are issued."""
+  cleared, no atomics are issued.  `per_wave`: `dot_out` has one double per
+  wave of all launches (`layered_dot_waves`), stored not accumulated."""
   dev = _dev(enc)
   if u.dim() != 1 or not u.is_contiguous() or not ext.is_contiguous():
     raise ValueError('layered assembly takes contiguous scalar fields')
   if ext.dtype != u.dtype:
     raise ValueError('u and the extended output differ in dtype')
   host = {k: _host(v, u.dtype) for k, v in host.items()}
+  waves = (layered_dot_waves(parts, P, enc.shape[0])
+           if per_wave and dot_out is not None else None)
+  if waves is not None and sum(waves) > dot_out.numel():
+    raise ValueError(f'{sum(waves)} waves but {dot_out.numel()} dot slots')
+  at = 0
   with torch.cuda.device(dev):
-    for part in parts:
+    for n, part in enumerate(parts):
+      dots = dot_out if waves is None else dot_out[at:at + waves[n]]
       args = _helmholtz_args(u, ext, enc, part, host, ndim, P, enc.shape[0],
-                             u.shape[0], lambda0, lambda1, (0, 0), dot_out,
-                             layered_extent=ext.numel())
+                             u.shape[0], lambda0, lambda1, (0, 0), dots,
+                             layered_extent=ext.numel(),
+                             dot_slots=0 if waves is None else waves[n])
+      if waves is not None:
+        at += waves[n]
       _lib.check(_lib.load().sfem_helmholtz_apply(ctypes.byref(args),
                                                   _stream(dev)),
                  'sfem_helmholtz_apply')
@@ -599,6 +625,29 @@ def cg_update_r_layered(r, ap_ext, layers, scalars, fuse_rr):
     _lib.check(_lib.load().sfem_cg_update_r_layered(
         _ptr(r), _ptr(ap_ext), r.numel(), ln, off, n, _ptr(scalars),
         int(fuse_rr), _dtype_code(r), _stream(dev)), 'sfem_cg_update_r_layered')
+
+
+def cg_update_r_layered_det(r, ap_ext, layers, scalars, rr_partials):
+  """The same with r.r left as STORED per-workgroup sums in `rr_partials`
+  (summed in index order by `cg_scalars_n(..., 8, ...)`): returns how many."""
+  dev = _dev(r, ap_ext, scalars, rr_partials)
+  ln, off, n = _layer_arrays(layers)
+  count = ctypes.c_int64(0)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_update_r_layered_det(
+        _ptr(r), _ptr(ap_ext), r.numel(), ln, off, n, _ptr(scalars),
+        _ptr(rr_partials), rr_partials.numel(), ctypes.byref(count),
+        _dtype_code(r), _stream(dev)), 'sfem_cg_update_r_layered_det')
+  return count.value
+
+
+def cg_scalars_n(scalars, phase, maxiter, tol, atol, partials, num_partials):
+  """`cg_scalars` over `num_partials` stored partial sums (phases 3, 4, 5, 8)."""
+  dev = _dev(scalars, partials)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_cg_scalars_n(
+        _ptr(scalars), phase, float(maxiter), float(tol), float(atol),
+        _ptr(partials), int(num_partials), _stream(dev)), 'sfem_cg_scalars_n')
 
 
 def fold_layers(ext, count, layers):

@@ -603,12 +603,16 @@ class HelmholtzOperator:
     return torch.zeros(plan.extent, dtype=self.fespace.dtype,
                        device=self.enc.device)
 
-  def apply_layered(self, u, ext, lambda0=0.0, lambda1=1.0, *, dot_out=None):
+  def apply_layered(self, u, ext, lambda0=0.0, lambda1=1.0, *, dot_out=None,
+                    per_wave=False):
     """`apply` for a scalar field with layered assembly: the unassembled
     contributions go to `ext` (from `new_extended`) as plain stores; the
     assembled value of node i is `ext[i]` plus its layers
     (`_ops.fold_layers(ext, N, plan.layers)`, or inside the consumer:
-    `_ops.cg_update_r_layered`).  Dirichlet rows are zero in every layer."""
+    `_ops.cg_update_r_layered`).  Dirichlet rows are zero in every layer.
+    `per_wave`: `dot_out` has `layered_dot_slots()` doubles and every wave
+    stores its share of u . out there (reproducible sum) instead of adding it
+    to one of SFEM_DOT_SLOTS slots atomically."""
     plan = self.layer_plan()
     if plan is None:
       raise NotImplementedError('this operator has no layer plan')
@@ -621,7 +625,14 @@ class HelmholtzOperator:
     return _ops.helmholtz_apply_layered(
         u.to(self.fespace.dtype).contiguous(), ext, self.enc, plan.parts,
         self.host, mesh.ndim, mesh.gridpoints_1d.num_points, lambda0, lambda1,
-        dot_out)
+        dot_out, per_wave)
+
+  def layered_dot_slots(self):
+    """Waves of one `apply_layered` (size of a per-wave `dot_out`)."""
+    mesh = self.fespace.mesh
+    return sum(_ops.layered_dot_waves(self.layer_plan().parts,
+                                      mesh.gridpoints_1d.num_points,
+                                      mesh.num_elements))
 
   def _parts_for(self, u):
     """Facet-table launches for scalar / component-major fields (the kernels
@@ -747,14 +758,17 @@ class FusedLinearOperator:
       return None
     return plan
 
-  def apply_layered_with_dot(self, u, partials):
+  def apply_layered_with_dot(self, u, partials, per_wave=False):
     """A(u) in layered form (an extended vector owned by this object, see
     `HelmholtzOperator.apply_layered`) + partial sums of u . A(u): for
     consumers that add the layers up themselves (`linalg.cg`)."""
     if self._ext is None:
       self._ext = self.op.new_extended()
     return self.op.apply_layered(u, self._ext, self.lambda0, self.lambda1,
-                                 dot_out=partials)
+                                 dot_out=partials, per_wave=per_wave)
+
+  def layered_dot_slots(self):
+    return self.op.layered_dot_slots()
 
 
 # ---------------------------------------------------------------------------

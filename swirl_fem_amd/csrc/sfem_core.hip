@@ -860,7 +860,8 @@ template <typename T, bool FUSE_RR, bool NT, bool STRIPED>
 __global__ void __launch_bounds__(512)
 cg_update_r_layered_kernel(T* __restrict__ r, const T* __restrict__ ap,
                            int64_t count, LayerDesc ld,
-                           double* __restrict__ scalars) {
+                           double* __restrict__ scalars,
+                           double* __restrict__ rr_partials) {
   if (scalars[7] != 0.0) return;
   using V = typename Vec16<T>::type;
   constexpr int VN = Vec16<T>::N;
@@ -893,10 +894,14 @@ cg_update_r_layered_kernel(T* __restrict__ r, const T* __restrict__ ap,
   }
   if (FUSE_RR) {
     const double total = block_sum(acc);
-    if (threadIdx.x == 0)
-      unsafeAtomicAdd(STRIPED ? &scalars[SFEM_CG_NSCALARS_NAMED +
-                                         (blockIdx.x & (SFEM_CG_RR_SLOTS - 1))]
-                              : &scalars[2], total);
+    if (threadIdx.x == 0) {
+      if (rr_partials)        // stored, summed in index order by phase 8
+        rr_partials[blockIdx.x] = total;
+      else
+        unsafeAtomicAdd(STRIPED ? &scalars[SFEM_CG_NSCALARS_NAMED +
+                                           (blockIdx.x & (SFEM_CG_RR_SLOTS - 1))]
+                                : &scalars[2], total);
+    }
   }
 }
 
@@ -949,10 +954,12 @@ template <typename T>
 static void launch_update_r_layered(int fuse_rr, bool nt, int grid,
                                     hipStream_t st, T* rr, const T* aa,
                                     int64_t count, const LayerDesc& ld,
-                                    double* scalars) {
+                                    double* scalars,
+                                    double* rr_partials = nullptr) {
 #define SFEM_UPDATE_RL(FUSE, NTV, STR)                                        \
   hipLaunchKernelGGL((cg_update_r_layered_kernel<T, FUSE, NTV, STR>),         \
-                     dim3(grid), dim3(512), 0, st, rr, aa, count, ld, scalars)
+                     dim3(grid), dim3(512), 0, st, rr, aa, count, ld, scalars, \
+                     rr_partials)
   if (fuse_rr == 2) {
     if (nt) SFEM_UPDATE_RL(true, true, true);
     else SFEM_UPDATE_RL(true, false, true);
@@ -1054,8 +1061,17 @@ __device__ __forceinline__ void cg_set_alpha(double* scalars, double pap) {
 
 __global__ void __launch_bounds__(256)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
-                 double atol, double* partials) {
+                 double atol, double* partials, int64_t num_partials,
+                 bool stored) {
   const int tid = threadIdx.x;
+  if (phase == 8) {
+    // gamma_new <- stored per-workgroup sums of r.r, in index order
+    double v = 0.0;
+    for (int64_t q = tid; q < num_partials; q += blockDim.x) v += partials[q];
+    const double total = block_sum(v);
+    if (tid == 0 && scalars[7] == 0.0) scalars[2] = total;
+    return;
+  }
   if (phase == 7) {
     // fold the striped r.r into the named slot NOW: the caller is about to
     // correct / all-reduce gamma_new (partitioned solves)
@@ -1078,9 +1094,9 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     double total = 0.0;
     if (phase == 5) {
       double v = 0.0;
-      for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) {
+      for (int64_t q = tid; q < num_partials; q += blockDim.x) {
         v += partials[q];
-        partials[q] = 0.0;          // the next apply accumulates again
+        if (!stored) partials[q] = 0.0;   // the next apply accumulates again
       }
       total = block_sum(v);
     }
@@ -1099,7 +1115,7 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
   }
   if (phase == 3 || phase == 4) {   // p.Ap <- sum of the fused partial sums
     double v = 0.0;
-    for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) v += partials[q];
+    for (int64_t q = tid; q < num_partials; q += blockDim.x) v += partials[q];
     const double total = block_sum(v);
     if (tid == 0 && scalars[7] == 0.0) {
       scalars[1] = total;
@@ -1107,7 +1123,7 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     }
     return;
   }
-  if (partials && (phase == 1 || phase == 2))
+  if (partials && !stored && (phase == 1 || phase == 2))
     for (int q = tid; q < SFEM_DOT_SLOTS; q += blockDim.x) partials[q] = 0.0;
   if (tid != 0) return;
   if (phase == 2) {
@@ -1524,6 +1540,37 @@ int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
   return SFEM_OK;
 }
 
+int sfem_cg_update_r_layered_det(void* r, const void* ap_ext, int64_t count,
+                                 const int64_t* layer_len,
+                                 const int64_t* layer_off, int num_layers,
+                                 double* scalars, double* rr_partials,
+                                 int64_t rr_capacity, int64_t* num_rr,
+                                 int dtype, sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && scalars && rr_partials && num_rr &&
+                   rr_capacity >= 1,
+               "sfem_cg_update_r_layered_det: bad arguments");
+  *num_rr = 0;
+  if (count == 0) return SFEM_OK;
+  SFEM_REQUIRE(r && ap_ext, "sfem_cg_update_r_layered_det: null pointer");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_cg_update_r_layered_det: unknown dtype %d", dtype);
+  LayerDesc ld;
+  const int rc = make_layer_desc("sfem_cg_update_r_layered_det", layer_len,
+                                 layer_off, num_layers, count,
+                                 dtype == SFEM_F64 ? 2 : 4, &ld);
+  if (rc != SFEM_OK) return rc;
+  DISPATCH_DTYPE(dtype, {
+    int grid = stream_grid(count, 512 * 2);
+    if (grid > rr_capacity) grid = (int)rr_capacity;
+    *num_rr = grid;
+    launch_update_r_layered<T>(1, streams_past_caches(count, sizeof(T)), grid,
+                               as_stream(stream), (T*)r, (const T*)ap_ext,
+                               count, ld, scalars, rr_partials);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
 int sfem_fold_layers(void* out_ext, int64_t count, const int64_t* layer_len,
                      const int64_t* layer_off, int num_layers, int dtype,
                      sfem_stream_t stream) {
@@ -1674,7 +1721,20 @@ int sfem_cg_scalars(double* scalars, int phase, double maxiter, double tol,
                "sfem_cg_scalars: bad arguments");
   hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
                      as_stream(stream), scalars, phase, maxiter, tol, atol,
-                     partials);
+                     partials, (int64_t)SFEM_DOT_SLOTS, false);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_cg_scalars_n(double* scalars, int phase, double maxiter, double tol,
+                      double atol, double* partials, int64_t num_partials,
+                      sfem_stream_t stream) {
+  SFEM_REQUIRE(scalars && partials && num_partials >= 1 &&
+                   (phase == 3 || phase == 4 || phase == 5 || phase == 8),
+               "sfem_cg_scalars_n: phases 3, 4, 5, 8 over stored partial sums");
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
+                     as_stream(stream), scalars, phase, maxiter, tol, atol,
+                     partials, num_partials, true);
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

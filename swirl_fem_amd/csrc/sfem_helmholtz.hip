@@ -245,6 +245,7 @@ struct HelmholtzCall {
   const int32_t* chain_elems = nullptr;
   int64_t num_chains = 0;
   int64_t layered_extent = 0;
+  int64_t dot_slots = 0;
 };
 
 template <typename T>
@@ -279,6 +280,7 @@ static int run_helmholtz(const HelmholtzCall& c, hipStream_t stream) {
     fp.chain_off = c.chain_offsets;
     fp.chain_elems = c.chain_elems;
     fp.layered = c.layered_extent > 0;
+    fp.dot_slots = c.dot_slots;
     if (fp.layered)       // positions in the extended vector decide the
       return dispatch_helmholtz_facet<T>(   // addressing width, scalar only
           fp, c.P, c.geo_mode,
@@ -477,6 +479,12 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
                    "sfem_helmholtz_apply: layered assembly takes scalar "
                    "fields and clears nothing");
       c.layered_extent = a->layered_extent;
+      SFEM_REQUIRE(a->dot_slots >= 0, "sfem_helmholtz_apply: negative dot_slots");
+      c.dot_slots = a->dot_slots;
+    } else {
+      SFEM_REQUIRE(a->dot_slots == 0,
+                   "sfem_helmholtz_apply: dot_slots goes with layered "
+                   "assembly");
     }
     if (a->chain_offsets) {
       SFEM_REQUIRE(a->chain_elems && a->num_chains > 0 &&

@@ -77,6 +77,12 @@ struct FacetParams {
   // so all results leave as plain stores; the consumer adds the layers up
   // (`sfem_cg_update_r_layered`, `sfem_fold_layers`).  Scalar fields.
   int layered;
+  // layered launches: > 0 = `dot_out` holds this many doubles, one per wave of
+  // the launch; every wave STORES its partial sum of u . out at its own index
+  // (nothing accumulated, nothing to clear: the sum over the slots in index
+  // order is bitwise reproducible); 0 = SFEM_DOT_SLOTS atomically
+  // accumulated slots
+  int64_t dot_slots;
 };
 
 constexpr uint32_t FACET_SKIP = 0x40000000u;   // layered: class is not written
@@ -924,10 +930,13 @@ helmholtz_facet_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   if (prm.dot_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
-    if ((w.lane & 63) == 0)
-      unsafeAtomicAdd(&prm.dot_out[(blockIdx.x * L::WAVES + (w.lane >> 6)) &
-                                   (SFEM_DOT_SLOTS - 1)],
-                      udot);
+    if ((w.lane & 63) == 0) {
+      const int64_t wave = (int64_t)blockIdx.x * L::WAVES + (w.lane >> 6);
+      if (LAY && prm.dot_slots > 0)
+        prm.dot_out[wave] = udot;
+      else
+        unsafeAtomicAdd(&prm.dot_out[wave & (SFEM_DOT_SLOTS - 1)], udot);
+    }
   }
 }
 
@@ -1041,10 +1050,13 @@ helmholtz_chain_kernel(FacetParams<T> prm, typename ELEM::Mat dm) {
   if (prm.dot_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) udot += __shfl_down(udot, off, 64);
-    if ((w.lane & 63) == 0)
-      unsafeAtomicAdd(&prm.dot_out[(blockIdx.x * L::WAVES + (w.lane >> 6)) &
-                                   (SFEM_DOT_SLOTS - 1)],
-                      udot);
+    if ((w.lane & 63) == 0) {
+      const int64_t wave = (int64_t)blockIdx.x * L::WAVES + (w.lane >> 6);
+      if (LAY && prm.dot_slots > 0)
+        prm.dot_out[wave] = udot;
+      else
+        unsafeAtomicAdd(&prm.dot_out[wave & (SFEM_DOT_SLOTS - 1)], udot);
+    }
   }
 }
 
@@ -1131,6 +1143,13 @@ int launch_helmholtz_facet(const FacetParams<T>& prm, int geo_mode,
     return SFEM_EINVAL;
   }
   const unsigned g = (unsigned)groups;
+  if (prm.dot_out && prm.layered && prm.dot_slots > 0 &&
+      groups * FacetLayout<P>::WAVES > prm.dot_slots) {
+    set_error("helmholtz (facet): %lld waves but %lld dot slots",
+              (long long)(groups * FacetLayout<P>::WAVES),
+              (long long)prm.dot_slots);
+    return SFEM_EINVAL;
+  }
   const bool mass = prm.lambda0 != T(0);
   // fields of 4 GiB and more take the 64-bit addressing instantiations
   // (SFEM_FACET_OFF64=1 forces them: tests)

@@ -64,6 +64,7 @@ MAX_KEPT_RUNNERS = 6   # solver states a `workspace` of `cg` holds at most
 # vectors below this size are served by the caches: the lazy x update would
 # only cost memory there (same threshold as the non-temporal vector kernels)
 LAZY_X_MIN_BYTES = 1 << 28
+RR_PARTIALS = 1 << 16      # stored r.r sums: one per workgroup of the r update
 
 
 class _Scalars:
@@ -180,6 +181,15 @@ class CGRunner:
         interface is None and self._p.dim() == 1 and
         hasattr(A, 'apply_layered_with_dot')):
       self.layered = A.layer_plan()
+    # ... and with the two inner products of the iteration summed from STORED
+    # partial sums in a fixed order (one double per wave of the apply, one per
+    # workgroup of the r update) the whole iteration is bitwise reproducible
+    # from run to run; costs one more scalar launch per iteration
+    self.det = None
+    if self.layered is not None and switches.get('SFEM_DETERMINISTIC') != '0':
+      self.det = (torch.zeros(A.layered_dot_slots(), dtype=torch.float64,
+                              device=device),
+                  torch.zeros(RR_PARTIALS, dtype=torch.float64, device=device))
     # Lazy solution update (`sfem_cg_update_xp_lazy`): x is touched every m-th
     # iteration only, the directions in between wait in a ring -- bitwise the
     # same x, 4.25 instead of 5 vector passes in the x / p update at m = 4.
@@ -284,7 +294,11 @@ class CGRunner:
     A, M, dot_fn, reduce_fn = self.A, self.M, self.dot_fn, self.reduce_fn
     args = (self.maxiter, self.tol, self.atol, self.parts)
     merged = self.fused_dot and reduce_fn is None
-    if self.fused_dot:
+    if self.fused_dot and self.det is not None:
+      Ap = A.apply_layered_with_dot(self.p, self.det[0], per_wave=True)
+      _ops.cg_scalars_n(s.t, 5, self.maxiter, self.tol, self.atol,
+                        self.det[0], self.det[0].numel())
+    elif self.fused_dot:
       Ap = (A.apply_layered_with_dot(self.p, s.partials)
             if self.layered is not None
             else A.apply_with_dot(self.p, s.partials))
@@ -321,7 +335,12 @@ class CGRunner:
         _ops.cg_scalars(s.t, 1, *args)
       self.issued += 1
       return
-    if self.layered is not None:
+    if self.layered is not None and self.det is not None and self.fuse_rr:
+      n = _ops.cg_update_r_layered_det(self.r, Ap, self.layered.layers, s.t,
+                                       self.det[1])
+      _ops.cg_scalars_n(s.t, 8, self.maxiter, self.tol, self.atol,
+                        self.det[1], n)
+    elif self.layered is not None:
       _ops.cg_update_r_layered(self.r, Ap, self.layered.layers, s.t,
                                self.fuse_rr)
     else:

@@ -46,6 +46,11 @@ SWITCHES = {
     'SFEM_LAYERED': ('1', 'core/operators.py',
                      '0: CG keeps the atomic assembly; force: layered '
                      'assembly also for elements with stored factors'),
+    'SFEM_DETERMINISTIC': ('1', 'linalg/cg.py',
+                           '0: with layered assembly the two inner products '
+                           'of a CG iteration still accumulate their partial '
+                           'sums with atomics (not bitwise reproducible; one '
+                           'scalar launch less per iteration)'),
     'SFEM_LAZY_X': ('4', 'linalg/cg.py',
                     'directions the CG keeps before it adds them to x '
                     '(vectors of 256 MB and more; 0 or 1: x += alpha p every '
