@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void cg_set_alpha(double* scalars, double pap) {
   scalars[2] = 0.0;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
                  double atol, double* partials, int64_t num_partials,
                  bool stored) {
@@ -1732,7 +1732,10 @@ int sfem_cg_scalars_n(double* scalars, int phase, double maxiter, double tol,
   SFEM_REQUIRE(scalars && partials && num_partials >= 1 &&
                    (phase == 3 || phase == 4 || phase == 5 || phase == 8),
                "sfem_cg_scalars_n: phases 3, 4, 5, 8 over stored partial sums");
-  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
+  // one workgroup sums tens of thousands of stored values: 1024 threads keep
+  // its loads few and independent (32 per thread at config 2)
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1),
+                     dim3(num_partials > 4096 ? 1024 : 256), 0,
                      as_stream(stream), scalars, phase, maxiter, tol, atol,
                      partials, num_partials, true);
   SFEM_LAUNCH_CHECK();

@@ -190,6 +190,7 @@ class CGRunner:
       self.det = (torch.zeros(A.layered_dot_slots(), dtype=torch.float64,
                               device=device),
                   torch.zeros(RR_PARTIALS, dtype=torch.float64, device=device))
+      self._reproducible_start(b, z)
     # Lazy solution update (`sfem_cg_update_xp_lazy`): x is touched every m-th
     # iteration only, the directions in between wait in a ring -- bitwise the
     # same x, 4.25 instead of 5 vector passes in the x / p update at m = 4.
@@ -209,6 +210,16 @@ class CGRunner:
       self._shape = tuple(self.r.shape)
     self.issued = 0
     self._graph = None
+
+  def _reproducible_start(self, b, z):
+    """b.b and gamma_0 = r.z again, as tree reductions without atomics (the
+    device dot accumulates its workgroups' sums in arrival order), and the
+    stopping rule re-initialised from them: the start of a reproducible solve."""
+    s, S = self.s, _Scalars
+    tree = lambda u, v: (u.double() * v.double()).sum()
+    s.t[S.BB] = tree(b, b)
+    s.t[S.GAMMA] = tree(self.r, z)
+    _ops.cg_scalars(s.t, 2, self.maxiter, self.tol, self.atol, self.parts)
 
   @property
   def vector_passes(self):
@@ -277,6 +288,8 @@ class CGRunner:
       _map(lambda pp, rr: pp.copy_(rr), self.p, self.r)
     s.dot_into(S.GAMMA, self.r, z, self.dot_fn, self.reduce_fn, self.interface)
     _ops.cg_scalars(s.t, 2, self.maxiter, self.tol, self.atol, self.parts)
+    if self.det is not None:
+      self._reproducible_start(b, z)
     if self.mean is not None:
       self.mean[2].zero_()
     self.issued = 0

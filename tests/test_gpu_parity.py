@@ -1434,8 +1434,12 @@ def test_cg_lazy_solution_update_is_bitwise_the_same(dtype, m, monkeypatch):
   iterations (the pending terms are added when x is read), same iteration
   count, also across `restart` and when somebody peeks at x mid-batch."""
   from swirl_fem_amd.linalg import cg as cg_mod
-  rp = make_case(3, 3, 5, seed=3)
-  mesh, fes, _ = spaces(rp, 5, 5, 'gll', dtype)
+  # (two separate solves are only bitwise comparable when nothing in them
+  # depends on the arrival order of atomics: a P = 6 mesh takes the layered
+  # assembly and the stored partial sums of `CGRunner.det`)
+  monkeypatch.setenv('SFEM_CHAIN_LEN', '3')
+  rp = make_case(3, 3, 6, seed=3)
+  mesh, fes, _ = spaces(rp, 6, 6, 'gll', dtype)
   bmask = mesh.physical_masks['boundary']
   op = fes.helmholtz_operator(bmask)
   A = op.linear_operator(0.3, 1.0)
@@ -1444,6 +1448,7 @@ def test_cg_lazy_solution_update_is_bitwise_the_same(dtype, m, monkeypatch):
   monkeypatch.setenv('SFEM_LAZY_X', '0')
   plain = cg_mod.CGRunner(A, b, tol=0.0, maxiter=10 ** 6)
   assert plain.lazy is None and plain.vector_passes == 8
+  assert plain.layered is not None and plain.det is not None
   xs = []
   for _ in range(11):
     plain.step()
