@@ -8,6 +8,7 @@ excluded as warm-up), CG iteration counts, DOFs.  Not the contract bench
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from swirl_fem_amd import switches
 from swirl_fem_amd.examples import navier_stokes_driver as drv
 
 CASES = {
@@ -57,6 +58,8 @@ for key in (sys.argv[1:] or ['cavity', 'tgv16']):
     kolmogorov()
     continue
   c = CASES[key]; prof = {}
+  if os.environ.get('STEPS'):       # longer runs (SFEM_PRESSURE_PROJECTION needs history)
+    c['kw']['steps'] = int(os.environ['STEPS'])
   sem, u, p, diag = getattr(drv, c['fn'])(device='cuda:0', profile=prof, **c['kw'])
   steps = prof['step_s'][1:]
   nv = sem.velocity.mesh.num_nodes; d = sem.velocity.mesh.ndim
@@ -67,5 +70,7 @@ for key in (sys.argv[1:] or ['cavity', 'tgv16']):
       'cg_iterations_helmholtz_pressure': diag['cg_iterations'][1:],
       'max_divergence': diag['max_divergence'], 'dtype': 'f64',
       'hip_graphs': os.environ.get('SFEM_GRAPHS', '1') != '0',
+      'switches': switches.active(),
+      'step_ms': [round(1e3 * t, 2) for t in prof['step_s']],
       'peak_memory_gb': torch.cuda.max_memory_allocated() / 1e9}), flush=True)
   del sem, u, p; torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()

@@ -1059,6 +1059,24 @@ __device__ __forceinline__ void cg_set_alpha(double* scalars, double pap) {
   scalars[2] = 0.0;
 }
 
+// sum of partials[tid], partials[tid + bd], ... in that order, eight loads in
+// flight at a time (one workgroup sums tens of thousands of stored values: a
+// load per dependent add would cost a memory round trip each)
+__device__ __forceinline__ double strided_sum(const double* __restrict__ partials,
+                                              int64_t n) {
+  const int64_t bd = blockDim.x;
+  double v = 0.0;
+  for (int64_t q = threadIdx.x; q < n; q += 8 * bd) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      t[u] = q + u * bd < n ? partials[q + u * bd] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  return v;
+}
+
 __global__ void __launch_bounds__(1024)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
                  double atol, double* partials, int64_t num_partials,
@@ -1066,9 +1084,7 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
   const int tid = threadIdx.x;
   if (phase == 8) {
     // gamma_new <- stored per-workgroup sums of r.r, in index order
-    double v = 0.0;
-    for (int64_t q = tid; q < num_partials; q += blockDim.x) v += partials[q];
-    const double total = block_sum(v);
+    const double total = block_sum(strided_sum(partials, num_partials));
     if (tid == 0 && scalars[7] == 0.0) scalars[2] = total;
     return;
   }
@@ -1093,10 +1109,15 @@ cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
     // closes the open iteration when the host wants to look ([9] = open).
     double total = 0.0;
     if (phase == 5) {
-      double v = 0.0;
-      for (int64_t q = tid; q < num_partials; q += blockDim.x) {
-        v += partials[q];
-        if (!stored) partials[q] = 0.0;   // the next apply accumulates again
+      double v;
+      if (stored) {
+        v = strided_sum(partials, num_partials);
+      } else {
+        v = 0.0;
+        for (int64_t q = tid; q < num_partials; q += blockDim.x) {
+          v += partials[q];
+          partials[q] = 0.0;        // the next apply accumulates again
+        }
       }
       total = block_sum(v);
     }

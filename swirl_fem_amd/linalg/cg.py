@@ -62,9 +62,15 @@ def _as_vec(t):
 
 MAX_KEPT_RUNNERS = 6   # solver states a `workspace` of `cg` holds at most
 # vectors below this size are served by the caches: the lazy x update would
-# only cost memory there (same threshold as the non-temporal vector kernels)
+# only cost memory there (same threshold as the non-temporal vector kernels;
+# SFEM_LAZY_X_MIN_MB overrides it, the tests set 0)
 LAZY_X_MIN_BYTES = 1 << 28
 RR_PARTIALS = 1 << 16      # stored r.r sums: one per workgroup of the r update
+
+
+def _lazy_min_bytes():
+  mb = switches.get('SFEM_LAZY_X_MIN_MB')
+  return LAZY_X_MIN_BYTES if mb is None else int(float(mb) * (1 << 20))
 
 
 class _Scalars:
@@ -198,7 +204,7 @@ class CGRunner:
     m = int(switches.get('SFEM_LAZY_X'))
     if (m >= 2 and self.mean is None and isinstance(self._p, torch.Tensor) and
         self._p.is_contiguous() and
-        self._p.numel() * self._p.element_size() >= LAZY_X_MIN_BYTES):
+        self._p.numel() * self._p.element_size() >= _lazy_min_bytes()):
       m = min(m, _lib.SFEM_CG_LAZY_MAX)
       n = self._p.numel()
       ring = torch.empty((m, (n + 3) // 4 * 4), dtype=self._p.dtype,

@@ -159,6 +159,61 @@ class _NullspaceProjection:
     return b1, float(total)
 
 
+class _SolutionProjection:
+  """Successive right-hand sides (Fischer, "Projection techniques for
+  iterative solution of A x = b with successive right-hand sides", Comput.
+  Methods Appl. Mech. Engrg. 163, 1998): the pressure increments of the last
+  steps, E-orthonormalised, span a space that holds most of the next one.
+  `guess(b)` is the E-orthogonal projection of the solution onto that space
+  (= the best start CG can be given from it), `update` adds the part of the
+  new solution that was not in the space.  The stopping rule of the solve is
+  unchanged (`cg` tests r . M r against tol^2 b . b, whatever x0 is), so the
+  result agrees with the unprojected solve to the solver tolerance; what
+  changes is the iteration count.  Beyond the reference (whose stepper starts
+  every pressure solve from zero, navier_stokes.py:446-452): opt-in.
+
+  Storage: 2 L pressure vectors (x_i and E x_i); cost per step: one more
+  application of E and four passes over the basis -- against hundreds of
+  iterations."""
+
+  def __init__(self, size: int, dot):
+    self.size, self.dot = int(size), dot
+    self.X = self.W = None        # (l, Np) each
+    self.count = 0
+
+  def guess(self, b):
+    if self.count == 0:
+      return None
+    X = self.X[:self.count]
+    alpha = self.dot(X, b)                       # (l,)
+    return torch.mv(X.t(), alpha)
+
+  def update(self, x, x0, apply_e):
+    d = x if x0 is None else x - x0
+    if self.X is None:
+      self.X = torch.zeros((self.size,) + tuple(x.shape), dtype=x.dtype,
+                           device=x.device)
+      self.W = torch.zeros_like(self.X)
+    if self.count == self.size:
+      # full: start again from the newest solution (it carries what the old
+      # basis knew about the current time level)
+      self.count, d = 0, x
+    w = apply_e(d)
+    if self.count:
+      X, W = self.X[:self.count], self.W[:self.count]
+      beta = self.dot(X, w)
+      d = d - torch.mv(X.t(), beta)
+      w = w - torch.mv(W.t(), beta)
+    nrm2 = self.dot(d[None], w)[0]
+    ok = nrm2 > 0
+    scale = torch.where(ok, torch.rsqrt(torch.where(ok, nrm2,
+                                                    torch.ones_like(nrm2))),
+                        torch.zeros_like(nrm2))
+    self.X[self.count] = d * scale
+    self.W[self.count] = w * scale
+    self.count += 1
+
+
 def _pressure_mass_ones(sem, dtype, device):
   """(B 1, 1 . B 1) of the pressure space, built once."""
   key = ('pressure_mass_ones', dtype)
@@ -640,8 +695,16 @@ class StokesSEM:
                       time_order: int, alpha: float = 0.05, u_boundary=None,
                       pressure_preconditioner=None,
                       project_out_nullspace=True, tol: float = 1e-8,
-                      atol: float = 0) -> tuple[torch.Tensor, torch.Tensor, Any]:
-    """Evolves the Stokes system by one fractional step (reference :350-458)."""
+                      atol: float = 0, pressure_projection: int | None = None
+                      ) -> tuple[torch.Tensor, torch.Tensor, Any]:
+    """Evolves the Stokes system by one fractional step (reference :350-458).
+
+    `pressure_projection` (beyond the reference; None = the switch
+    SFEM_PRESSURE_PROJECTION, default 0 = off): number of earlier pressure
+    increments kept to start the pressure solve from their span
+    (`_SolutionProjection`); same result to the solver tolerance, fewer
+    iterations -- the state lives in this object, so use it for ONE time
+    series with fixed dt and time_order."""
     default_projection = pressure_preconditioner is None and \
         project_out_nullspace
     if default_projection:
@@ -709,11 +772,29 @@ class StokesSEM:
     u_star = self.filter(u_star, alpha=alpha)
 
     rhs = -self.D(u_star)
-    dp, info = _solve(diff, _PressureOperator(self, dt, time_order), rhs,
+    E_ = _PressureOperator(self, dt, time_order)
+    if pressure_projection is None:
+      pressure_projection = int(switches.get('SFEM_PRESSURE_PROJECTION'))
+    hist, dp0 = None, None
+    if pressure_projection > 0 and not diff:
+      key = ('pressure_projection', float(dt), int(time_order),
+             int(pressure_projection))
+      hist = self._cache.get(key)
+      if hist is None:
+        reduce = self._reduce_fn()
+        def dots(X, v):           # (l, Np) x (Np,) -> (l,), over all ranks
+          out = torch.mv(X, v)
+          return out if reduce is None else reduce(out)
+        hist = self._cache[key] = _SolutionProjection(pressure_projection,
+                                                      dots)
+      dp0 = hist.guess(rhs)
+    dp, info = _solve(diff, E_, rhs, x0=dp0,
                       M=pressure_preconditioner, tol=tol, atol=atol,
                       graph=small(rhs), reduce_fn=self._reduce_fn(),
                       **(keep('E', float(dt), int(time_order))
                          if default_projection and small(rhs) else {}))
+    if hist is not None:
+      hist.update(dp, dp0, E_)
     aux['dp_info'] = info
 
     u = u_star + self.Q(self.Dt(dp), dt=dt, time_order=time_order)

@@ -55,6 +55,9 @@ SWITCHES = {
                     'directions the CG keeps before it adds them to x '
                     '(vectors of 256 MB and more; 0 or 1: x += alpha p every '
                     'iteration)'),
+    'SFEM_LAZY_X_MIN_MB': (None, 'linalg/cg.py',
+                           'smallest vector (MiB) that gets the lazy x update '
+                           '(default 256; the tests set 0)'),
     'SFEM_SORTED_SCATTER': ('1', 'core/operators.py',
                             '0: index-row kernels issue their atomics in slot '
                             'order instead of node order'),
@@ -87,6 +90,12 @@ SWITCHES = {
     'SFEM_GRAPH_MAX_NUMEL': (str(1 << 25), 'navier_stokes/navier_stokes.py',
                              'largest vector (entries) whose solves are '
                              'replayed as graphs'),
+    'SFEM_PRESSURE_PROJECTION': ('0', 'navier_stokes/navier_stokes.py',
+                                 'number of earlier pressure increments the '
+                                 'steppers project the next pressure solve '
+                                 'onto (successive right-hand sides; 0 = off: '
+                                 "every solve starts from zero as in the "
+                                 'reference)'),
     # test-size knobs (tests/ only)
     'SFEM_TEST_FULL_N': ('64', 'tests/', 'elements per direction of the '
                          'full-size property tests'),

@@ -325,13 +325,14 @@ def test_block_plans_of_the_8_gpu_grid_are_symmetric():
   assert len(np.unique(allk)) == parts[0].num_global_nodes
 
 
-def _run_bench(*flags, timeout=600):
+def _run_bench(*flags, timeout=600, **extra_env):
   import json
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = {k: v for k, v in os.environ.items()
          if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+  env.update(extra_env)
   res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *flags],
                        env=env, capture_output=True, text=True,
                        timeout=timeout)
@@ -409,9 +410,13 @@ def test_bench_eight_ranks_with_real_kernels_on_one_gpu(flags, blocks):
   box allows six processes on its card.  `--verify` solves A x = A x* for a
   manufactured x* through the timed operator and solver on all ranks.
   Reference: core/premesh.py:170-222, core/gather_scatter.py:318-358."""
+  # (SFEM_LAZY_X_MIN_MB=0: the lazy x update that the 64^3 blocks of the
+  # real run take, on these small ones)
   res, line = _run_bench('--gpus', '8', '--backend', 'threads', *flags,
                          '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
-                         '--no-general', '--verify', timeout=900)
+                         '--no-general', '--verify', timeout=900,
+                         SFEM_LAZY_X_MIN_MB='0')
+  assert line['config']['switches'] == {'SFEM_LAZY_X_MIN_MB': '0'}
   assert res.returncode == 0, res.stderr[-3000:]
   assert sum(l.startswith('{') for l in res.stdout.splitlines()) == 1
   cfg = line['config']

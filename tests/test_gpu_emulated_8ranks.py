@@ -108,9 +108,10 @@ def _run_ranks(mail, rank_main):
   return results
 
 
-@pytest.mark.parametrize('n,P,dtype', [(2, 4, torch.float64),
-                                       (1, 12, torch.float32)])
-def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch, n, P, dtype):
+@pytest.mark.parametrize('n,P,dtype,lazy', [(2, 4, torch.float64, False),
+                                            (1, 12, torch.float32, False),
+                                            (2, 4, torch.float64, True)])
+def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch, n, P, dtype, lazy):
   """(1, 12, fp32) is BASELINE config 5 in miniature: p = 11 Helmholtz in
   single precision on the 2 x 2 x 2 grid."""
   from swirl_fem_amd.core.fespace import FiniteElementSpace
@@ -120,6 +121,8 @@ def test_partitioned_cg_on_the_8_gpu_topology(monkeypatch, n, P, dtype):
   grid = (2, 2, 2)
   f64 = dtype == torch.float64
   tol = 1e-12 if f64 else 1e-6
+  if lazy:      # the x update of the 64^3 blocks of `bench.py --gpus 8`
+    monkeypatch.setenv('SFEM_LAZY_X_MIN_MB', '0')
   mail = Mailbox(WORLD)
   _install_transport(monkeypatch, mail)
 

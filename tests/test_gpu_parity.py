@@ -1454,7 +1454,7 @@ def test_cg_lazy_solution_update_is_bitwise_the_same(dtype, m, monkeypatch):
     plain.step()
     xs.append(plain.x.clone())
   monkeypatch.setenv('SFEM_LAZY_X', str(m))
-  monkeypatch.setattr(cg_mod, 'LAZY_X_MIN_BYTES', 0)
+  monkeypatch.setenv('SFEM_LAZY_X_MIN_MB', '0')
   for k in range(1, 12):          # k iterations, x read once at the end
     run = cg_mod.CGRunner(A, b, tol=0.0, maxiter=10 ** 6)
     assert run.lazy is not None and run.lazy[0].shape[0] == m

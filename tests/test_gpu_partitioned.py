@@ -82,12 +82,18 @@ def _worker(rank, world, port, grid, n, P, dtype_name, results):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('grid,n,P,dtype_name', [
-    ((2, 1, 1), 3, 4, 'float64'),
-    ((2, 2, 1), 2, 5, 'float64'),
-    ((2, 1, 1), 2, 8, 'float32'),
+@pytest.mark.parametrize('grid,n,P,dtype_name,lazy', [
+    ((2, 1, 1), 3, 4, 'float64', False),
+    ((2, 2, 1), 2, 5, 'float64', False),
+    ((2, 1, 1), 2, 8, 'float32', False),
+    # the lazy solution update (vectors of 256 MB and more: every 64^3 block
+    # of the scaling run) next to the all-reduces and the interface correction
+    ((2, 2, 1), 2, 5, 'float64', True),
+    ((2, 1, 1), 2, 8, 'float32', True),
 ])
-def test_partitioned_cg_on_one_gpu(grid, n, P, dtype_name):
+def test_partitioned_cg_on_one_gpu(grid, n, P, dtype_name, lazy, monkeypatch):
+  if lazy:        # (the rank processes inherit the environment)
+    monkeypatch.setenv('SFEM_LAZY_X_MIN_MB', '0')
   world = int(np.prod(grid))
   port = _free_port()
   with mp.Manager() as mgr:

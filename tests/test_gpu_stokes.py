@@ -359,3 +359,31 @@ def test_kept_solver_graphs_give_the_same_steps(monkeypatch):
       it1, it0)
   assert relerr(u1, u0_.cpu().numpy()) < 1e-8
   assert relerr(p1, p0_.cpu().numpy()) < 1e-6
+
+
+def test_pressure_projection_cuts_iterations():
+  """Successive right-hand-side projection of the pressure solve
+  (`stokes_one_step(pressure_projection=L)`, beyond the reference, opt-in):
+  same velocity and pressure as the unprojected stepper to the solver
+  tolerance, clearly fewer pressure iterations once a few steps of history
+  exist.  3D Taylor-Green, periodic, order 5."""
+  from swirl_fem_amd.examples import navier_stokes_driver as drv
+  kw = dict(n=4, order=5, reynolds=100.0, dt=2e-3, steps=10, time_order=3,
+            device=DEV, tol=1e-9)
+  sem0, u0, p0, d0 = drv.taylor_green(**kw)
+  sem1, u1, p1, d1 = drv.taylor_green(pressure_projection=6, **kw)
+  assert float((u1 - u0).abs().max()) < 1e-7 * float(u0.abs().max())
+  pm = lambda p: p - p.mean()
+  assert float((pm(p1) - pm(p0)).abs().max()) < 1e-5 * float(
+      pm(p0).abs().max())
+  it0 = [b for _, b in d0['cg_iterations']]
+  it1 = [b for _, b in d1['cg_iterations']]
+  assert it1[0] == it0[0]                  # nothing to project onto yet
+  assert sum(it1[4:]) * 2 <= sum(it0[4:]), (it0, it1)
+  assert abs(d1['kinetic_energy'][-1] - d0['kinetic_energy'][-1]) < 1e-8 * abs(
+      d0['kinetic_energy'][-1])
+  # the history lives in the stepper object, keyed by (dt, order, L)
+  assert any(isinstance(k, tuple) and k and k[0] == 'pressure_projection'
+             for k in sem1._cache)
+  assert not any(isinstance(k, tuple) and k and k[0] == 'pressure_projection'
+                 for k in sem0._cache)
