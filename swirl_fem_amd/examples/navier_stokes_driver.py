@@ -20,6 +20,7 @@ import time
 import numpy as np
 import torch
 
+from swirl_fem_amd import switches
 from swirl_fem_amd.common.premesh_commons import box_mesh, unit_cube_mesh
 from swirl_fem_amd.navier_stokes import navier_stokes
 from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
@@ -28,7 +29,7 @@ from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
 def navier_stokes_step(sem: StokesSEM, us, ps, Cus, *, reynolds: float,
                        dt: float, time_order: int, forcing=None,
                        u_boundary=None, tol=1e-5, atol=1e-4, alpha=0.05,
-                       pressure_projection=None):
+                       pressure_projection=None, pressure_preconditioner=None):
   """One BDFk/EXT(k-1) step (datagen.py:90-102).
 
   Args:
@@ -44,8 +45,19 @@ def navier_stokes_step(sem: StokesSEM, us, ps, Cus, *, reynolds: float,
   f = -Cu
   if forcing is not None:
     f = f + sem.B(forcing)
+  # beyond the reference: a preconditioner by name for its
+  # `pressure_preconditioner` hook (None / 'projection' = the reference's
+  # nullspace projection; 'schwarz': navier_stokes/pressure_preconditioner.py)
+  if pressure_preconditioner is None:
+    pressure_preconditioner = switches.get('SFEM_PRESSURE_PC')
+  if isinstance(pressure_preconditioner, str):
+    from swirl_fem_amd.navier_stokes import pressure_preconditioner as pc
+    pressure_preconditioner = pc.make_pressure_preconditioner(
+        sem, pressure_preconditioner, dt, time_order)
   u, p, aux = sem.stokes_one_step(us, ps, f, mu=1.0 / reynolds, dt=dt,
                                   time_order=time_order, alpha=alpha,
+                                  pressure_preconditioner=
+                                  pressure_preconditioner,
                                   u_boundary=u_boundary, tol=tol, atol=atol,
                                   pressure_projection=pressure_projection)
   return u, p, sem.C(u), aux
@@ -88,7 +100,8 @@ def _histories(sem, u0, p0, time_order):
 
 def lid_driven_cavity(n=8, order=5, reynolds=100.0, dt=1e-3, steps=10,
                       time_order=3, device=None, premesh=None, tol=1e-8,
-                      profile=None, pressure_projection=None):
+                      profile=None, pressure_projection=None,
+                      pressure_preconditioner=None):
   """2D lid-driven cavity on [0,1]^2; returns (sem, u, p, diagnostics)."""
   timer = _StepTimer(profile, device)
   pm = premesh if premesh is not None else unit_cube_mesh(n, ndim=2)
@@ -109,7 +122,8 @@ def lid_driven_cavity(n=8, order=5, reynolds=100.0, dt=1e-3, steps=10,
     u, p, Cu, aux = navier_stokes_step(
         sem, us, ps, Cus, reynolds=reynolds, dt=dt, time_order=time_order,
         u_boundary=u_b, tol=tol, atol=0.0,
-        pressure_projection=pressure_projection)
+        pressure_projection=pressure_projection,
+        pressure_preconditioner=pressure_preconditioner)
     us, ps, Cus = us[1:] + (u,), ps[1:] + (p,), Cus[1:] + (Cu,)
     timer.step_done()
     iters.append((aux['u_star_info']['num_iterations'],
@@ -122,7 +136,8 @@ def lid_driven_cavity(n=8, order=5, reynolds=100.0, dt=1e-3, steps=10,
 
 
 def taylor_green(n=4, order=3, reynolds=100.0, dt=1e-2, steps=5, time_order=3,
-                 device=None, tol=1e-8, profile=None, pressure_projection=None):
+                 device=None, tol=1e-8, profile=None, pressure_projection=None,
+                 pressure_preconditioner=None):
   """3D Taylor-Green vortex on the periodic box [0, 2 pi]^3 (`n` elements
   per direction, or one count per direction)."""
   timer = _StepTimer(profile, device)
@@ -145,7 +160,8 @@ def taylor_green(n=4, order=3, reynolds=100.0, dt=1e-2, steps=5, time_order=3,
   for _ in range(steps):
     u, p, Cu, aux = navier_stokes_step(
         sem, us, ps, Cus, reynolds=reynolds, dt=dt, time_order=time_order,
-        tol=tol, atol=0.0, pressure_projection=pressure_projection)
+        tol=tol, atol=0.0, pressure_projection=pressure_projection,
+        pressure_preconditioner=pressure_preconditioner)
     us, ps, Cus = us[1:] + (u,), ps[1:] + (p,), Cus[1:] + (Cu,)
     timer.step_done()
     energy.append(float(0.5 * (w * u ** 2).sum()))
@@ -159,7 +175,7 @@ def taylor_green(n=4, order=3, reynolds=100.0, dt=1e-2, steps=5, time_order=3,
 def taylor_green_blocks(n=4, order=3, block_grid=(2, 2, 2), rank=None,
                         reynolds=100.0, dt=1e-2, steps=5, time_order=3,
                         device=None, tol=1e-8, profile=None,
-                        pressure_projection=None):
+                        pressure_projection=None, pressure_preconditioner=None):
   """BASELINE config 4: the 3D Taylor-Green vortex on the triply periodic box
   [0, 2 pi]^3, one `n^3`-element block per rank (`block_grid` ranks, launched
   with torch.distributed; 2 x 2 x 2 blocks of 64^3 elements are the 128^3
@@ -192,7 +208,8 @@ def taylor_green_blocks(n=4, order=3, block_grid=(2, 2, 2), rank=None,
   for _ in range(steps):
     u, p, Cu, aux = navier_stokes_step(
         sem, us, ps, Cus, reynolds=reynolds, dt=dt, time_order=time_order,
-        tol=tol, atol=0.0, pressure_projection=pressure_projection)
+        tol=tol, atol=0.0, pressure_projection=pressure_projection,
+        pressure_preconditioner=pressure_preconditioner)
     us, ps, Cus = us[1:] + (u,), ps[1:] + (p,), Cus[1:] + (Cu,)
     energy.append(float(sem._global_sum(0.5 * (w * u ** 2).sum().reshape(1))))
     iters.append((aux['u_star_info']['num_iterations'],

@@ -1,0 +1,248 @@
+"""Two-level Schwarz preconditioner for the pressure operator E = D Q D^T.
+
+The reference's stepper takes a `pressure_preconditioner` callable
+(navier_stokes/navier_stokes.py:354, :419-420, :449-452) and ships none beyond
+the projection that removes the constant mode (:73-78); with it the pressure
+solve of a P_N - P_{N-2} discretisation needs hundreds of iterations per step
+(380 - 680 on one 64^3 block of BASELINE config 4), and their number grows
+with the polynomial order and with the number of elements across the domain.
+This module is an opt-in for that hook -- results agree to the solver
+tolerance, the default stays the reference's:
+
+    M^-1 r = P ( sum_e R_e^T E~_e^+ R_e r  +  R_0^T E_0^+ R_0 r )
+
+* local part: the pressure nodes of an element belong to it alone, so the
+  diagonal block E_ee = D_e Q D_e^T is a natural subdomain problem.  With the
+  element taken as a box in its own coordinates and Q (= (dt / beta) x inverse
+  assembled velocity mass x Dirichlet mask) as a tensor product along the
+  element's axes -- both exact on Cartesian meshes, an approximation elsewhere
+  that only costs iterations -- E_ee = sum_d k_d^2 (A_d in direction d) (x) (B
+  in the others) with 1D matrices A_d = G diag(f_d) G^T, B_d = H diag(f_d) H^T,
+  G = I^T W D and H = I^T W (I: pressure -> velocity nodes, W: quadrature
+  weights, D: 1D derivative).  The generalised eigenvectors of (A_d, B_d)
+  diagonalise it: two small tensor contractions per direction and a division
+  (fast diagonalisation, Lynch, Rice & Thomas 1964; for E: Fischer, J. Comput.
+  Phys. 133, 1997).  The element's constant mode is left to the coarse level
+  (pseudo-inverse);
+* coarse part: R_0 sums a vector over each element (piecewise constants),
+  E_0 = R_0 E R_0^T is assembled exactly from the elements' boundary fluxes
+  int_e d(phi_n)/dx_c (sparse, 27 entries per row on a structured mesh) and
+  solved by a fixed number of Jacobi-preconditioned CG iterations;
+* P: the reference's nullspace projection.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from swirl_fem_amd.navier_stokes import navier_stokes as ns
+
+
+def _centre_cofactors(xe, P, d):
+  """(E, d) squared row norms k_a^2 = sum_c (det J dxi_a / dx_c)^2 of the
+  Jacobian of the element's multilinear map at its centre."""
+  E = xe.shape[0]
+  x = xe.reshape((E,) + (P,) * d + (d,))
+  rows = []
+  for a in range(d):
+    hi = x.select(1 + a, P - 1)
+    lo = x.select(1 + a, 0)
+    diff = hi - lo                                  # (E, P.., d) over the face
+    # corners of the face: mean over the 2^(d-1) edges along axis a
+    corner = diff
+    for ax in range(d - 1):
+      corner = corner.index_select(1 + ax, torch.tensor(
+          [0, P - 1], device=x.device))
+    rows.append(corner.reshape(E, -1, d).mean(dim=1) / 2)
+  J = torch.stack(rows, dim=1)                      # J[a, c] = dx_c / dxi_a
+  det = torch.linalg.det(J)
+  K = det[:, None, None] * torch.linalg.inv(J).transpose(1, 2)  # K[a][c]
+  return (K ** 2).sum(dim=2)
+
+
+class SchwarzPressurePreconditioner:
+  """`z = M^-1 r` for `cg(E, b, M=...)`; see the module docstring."""
+
+  def __init__(self, sem, dt, time_order, coarse_iterations=None):
+    self.sem = sem
+    vmesh = sem.velocity.mesh
+    pmesh = sem.pressure.pspace.mesh
+    d = self.d = vmesh.ndim
+    P = self.P = vmesh.gridpoints_1d.num_points
+    Pp = self.Pp = pmesh.gridpoints_1d.num_points
+    if sem.is_partitioned:
+      raise NotImplementedError('Schwarz pressure preconditioner on a '
+                                'partitioned mesh')
+    dev, dtype = vmesh.device, vmesh.node_coords.dtype
+    E = vmesh.num_elements
+    self.pel = pmesh.elements.to(torch.int64)       # (E, Pp^d)
+    # --- Q on the velocity nodes (what `StokesSEM.E` applies between D^T
+    # and D): (dt / beta) / QQ^T(mass), zero on Dirichlet rows
+    beta_k = float(ns.bdfk_coeffs(time_order)[-1])
+    mass = sem.velocity.exchange(sem.velocity_mass_diag)
+    q = (dt / beta_k) / mass * sem.velocity.interior_mask
+    q = q[:, 0].contiguous()                        # same for every component
+    vel = vmesh.elements.to(torch.int64)
+    qloc = q[vel].reshape((E,) + (P,) * d)          # (E, P, P[, P])
+    ref = qloc[(slice(None),) + (1,) * d]           # an element-interior node
+    t = ref ** (1.0 / d)
+    f = []
+    for a in range(d):
+      idx = [slice(None)] + [1] * d
+      idx[1 + a] = slice(None)
+      f.append(qloc[tuple(idx)] / t[:, None] ** (d - 1))    # (E, P)
+    k2 = _centre_cofactors(vmesh.element_coords(), P, d)     # (E, d)
+    # --- 1D matrices
+    interp = np.asarray(sem.pressure.pspace.interpolator.
+                        _interpolation_matrix_1d())            # (P, Pp)
+    w = np.asarray(sem.velocity.vspace.quadrature.weights)
+    dmat = np.asarray(sem.velocity.vspace.interpolator.
+                      _differentiation_matrix_1d())
+    H = interp.T * w[None, :]                                   # (Pp, P)
+    G = H @ dmat
+    # --- generalised eigenproblems, one per distinct factor row
+    S_all, lam_all, case = [], [], []
+    offset = 0
+    for a in range(d):
+      fa = f[a].cpu().numpy()
+      scale = np.abs(fa).max(axis=1, keepdims=True)
+      key = np.round(fa / scale, 10) * scale        # exact on uniform meshes
+      uniq, inv = np.unique(key, axis=0, return_inverse=True)
+      A = np.einsum('pi,ci,qi->cpq', G, uniq, G)
+      B = np.einsum('pi,ci,qi->cpq', H, uniq, H)
+      L = np.linalg.cholesky(B)
+      Li = np.linalg.inv(L)
+      lam, V = np.linalg.eigh(Li @ A @ Li.transpose(0, 2, 1))
+      S = Li.transpose(0, 2, 1) @ V                 # S^T B S = I, S^T A S = lam
+      S_all.append(S)
+      lam_all.append(np.maximum(lam, 0.0))
+      case.append(inv.reshape(-1) + offset)
+      offset += len(uniq)
+    self.S = torch.as_tensor(np.concatenate(S_all), dtype=dtype, device=dev)
+    lam = torch.as_tensor(np.concatenate(lam_all), dtype=dtype, device=dev)
+    self.case = [torch.as_tensor(c, device=dev) for c in case]
+    # eigenvalues of the element blocks, pseudo-inverted
+    shape = lambda a: [E] + [Pp if b == a else 1 for b in range(d)]
+    ev = sum((k2[:, a, None] * lam[self.case[a]]).reshape(shape(a))
+             for a in range(d))
+    top = ev.reshape(E, -1).max(dim=1).values.reshape([E] + [1] * d)
+    self.inv_ev = torch.where(ev > 1e-10 * top, 1.0 / ev, torch.zeros_like(ev))
+    # --- coarse level
+    self._build_coarse(q, dtype, dev)
+    n1 = round(E ** (1.0 / d))
+    self.coarse_iterations = (int(coarse_iterations) if coarse_iterations
+                              else max(20, 3 * n1))
+    self.project = ns._NullspaceProjection(sem)
+
+  # ------------------------------------------------------------- coarse level
+  def _build_coarse(self, q, dtype, dev):
+    """E_0 = R_0 E R_0^T from the elements' flux vectors
+    g_e[n, c] = int_e d(phi_n)/dx_c (= D^T_local of the constant 1)."""
+    import scipy.sparse as sp
+    sem = self.sem
+    vmesh = sem.velocity.mesh
+    E, n = vmesh.elements.shape
+    d = self.d
+    ones = torch.ones((E, self.Pp ** d), dtype=dtype, device=dev)
+    g = sem.Dt_local(ones)                                       # (E, n, d)
+    # node classes: periodic images are one node for the operator
+    ids = vmesh.elements.to(torch.int64)
+    if vmesh.node_indices is not None:
+      ids = torch.as_tensor(vmesh.node_indices, device=dev).to(
+          torch.int64)[ids]
+    gmax = float(g.abs().max())
+    rows, cols, vals = [], [], []
+    for c in range(d):
+      nz = g[..., c].abs() > 1e-13 * gmax
+      e_idx, loc = torch.nonzero(nz, as_tuple=True)
+      rows.append(e_idx)
+      cols.append(ids[e_idx, loc] * d + c)
+      vals.append(g[e_idx, loc, c])
+    rows, cols, vals = (torch.cat(v).cpu().numpy() for v in (rows, cols, vals))
+    N = int(vmesh.num_nodes)
+    Gs = sp.csr_matrix((vals, (rows, cols)), shape=(E, N * d))
+    Gs.sum_duplicates()
+    # the representative of a class carries the operator's q
+    qn = np.repeat(q.cpu().numpy(), d)
+    E0 = (Gs.multiply(qn[None, :]) @ Gs.T).tocsr()
+    E0.sum_duplicates()
+    self.coarse_diag = torch.as_tensor(E0.diagonal(), dtype=dtype, device=dev)
+    self.E0 = torch.sparse_csr_tensor(
+        torch.as_tensor(E0.indptr, dtype=torch.int64),
+        torch.as_tensor(E0.indices, dtype=torch.int64),
+        torch.as_tensor(E0.data, dtype=dtype), size=E0.shape).to(dev)
+    # constants are in the kernel of E_0 when nothing pins the pressure
+    resid = np.abs(E0 @ np.ones(E)).max() / max(np.abs(E0.diagonal()).max(),
+                                                1e-300)
+    self.coarse_singular = bool(resid < 1e-8)
+
+  def _coarse_solve(self, b):
+    """`coarse_iterations` Jacobi-preconditioned CG iterations on E_0 y = b
+    (all on the device, no convergence test: a fixed linear-in-practice map)."""
+    if self.coarse_singular:
+      b = b - b.mean()
+    dinv = 1.0 / self.coarse_diag
+    x = torch.zeros_like(b)
+    r = b.clone()
+    z = dinv * r
+    p = z.clone()
+    rz = torch.dot(r, z)
+    tiny = torch.finfo(b.dtype).tiny
+    for _ in range(self.coarse_iterations):
+      Ap = torch.mv(self.E0, p)
+      alpha = rz / torch.clamp(torch.dot(p, Ap), min=tiny)
+      x = x + alpha * p
+      r = r - alpha * Ap
+      z = dinv * r
+      rz_new = torch.dot(r, z)
+      p = z + (rz_new / torch.clamp(rz, min=tiny)) * p
+      rz = rz_new
+    if self.coarse_singular:
+      x = x - x.mean()
+    return x
+
+  # -------------------------------------------------------------------- apply
+  def _mode(self, t, a, transpose):
+    """Contracts axis a of t (E, Pp, ..) with the element's S (or S^T)."""
+    S = self.S[self.case[a]]                          # (E, Pp, Pp)
+    if transpose:
+      S = S.transpose(1, 2)
+    t = t.movedim(1 + a, 1)
+    shape = t.shape
+    out = torch.bmm(S, t.reshape(shape[0], shape[1], -1)).reshape(shape)
+    return out.movedim(1, 1 + a)
+
+  def local_solve(self, r):
+    E, d, Pp = self.pel.shape[0], self.d, self.Pp
+    t = r[self.pel].reshape((E,) + (Pp,) * d)
+    for a in range(d):
+      t = self._mode(t, a, True)
+    t = t * self.inv_ev
+    for a in range(d):
+      t = self._mode(t, a, False)
+    z = torch.empty_like(r)
+    z[self.pel.reshape(-1)] = t.reshape(-1)
+    return z
+
+  def __call__(self, r):
+    z = self.local_solve(r)
+    rc = r[self.pel].sum(dim=1)
+    yc = self._coarse_solve(rc)
+    z = z.index_add(0, self.pel.reshape(-1),
+                    yc[:, None].expand(-1, self.pel.shape[1]).reshape(-1))
+    return self.project(z)
+
+
+def make_pressure_preconditioner(sem, name, dt, time_order):
+  """The preconditioner a driver asks for by name ('schwarz'), kept per
+  (dt, time_order) in the stepper object; None / 'projection' = the
+  reference's default."""
+  if name in (None, 'projection'):
+    return None
+  if name != 'schwarz':
+    raise ValueError(f'unknown pressure preconditioner {name!r}')
+  key = ('pressure_pc', name, float(dt), int(time_order))
+  if key not in sem._cache:
+    sem._cache[key] = SchwarzPressurePreconditioner(sem, dt, time_order)
+  return sem._cache[key]

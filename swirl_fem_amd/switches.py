@@ -90,6 +90,12 @@ SWITCHES = {
     'SFEM_GRAPH_MAX_NUMEL': (str(1 << 25), 'navier_stokes/navier_stokes.py',
                              'largest vector (entries) whose solves are '
                              'replayed as graphs'),
+    'SFEM_PRESSURE_PC': ('projection', 'examples/navier_stokes_driver.py',
+                         "pressure preconditioner of the drivers: 'projection' "
+                         "(the reference's nullspace projection) or 'schwarz' "
+                         '(element-wise fast diagonalisation + piecewise-'
+                         'constant coarse level, '
+                         'navier_stokes/pressure_preconditioner.py)'),
     'SFEM_PRESSURE_PROJECTION': ('0', 'navier_stokes/navier_stokes.py',
                                  'number of earlier pressure increments the '
                                  'steppers project the next pressure solve '
