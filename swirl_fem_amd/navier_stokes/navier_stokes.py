@@ -790,7 +790,10 @@ class StokesSEM:
       dp0 = hist.guess(rhs)
     dp, info = _solve(diff, E_, rhs, x0=dp0,
                       M=pressure_preconditioner, tol=tol, atol=atol,
-                      graph=small(rhs), reduce_fn=self._reduce_fn(),
+                      # (a caller's preconditioner may do things a recorded
+                      # iteration cannot hold: sparse products, host logic)
+                      graph=small(rhs) and default_projection,
+                      reduce_fn=self._reduce_fn(),
                       **(keep('E', float(dt), int(time_order))
                          if default_projection and small(rhs) else {}))
     if hist is not None:
