@@ -168,16 +168,49 @@ class SchwarzPressurePreconditioner:
     E0 = (Gs.multiply(qn[None, :]) @ Gs.T).tocsr()
     E0.sum_duplicates()
     self.coarse_diag = torch.as_tensor(E0.diagonal(), dtype=dtype, device=dev)
-    self.E0 = torch.sparse_csr_tensor(
-        torch.as_tensor(E0.indptr, dtype=torch.int64),
-        torch.as_tensor(E0.indices, dtype=torch.int64),
-        torch.as_tensor(E0.data, dtype=dtype), size=E0.shape).to(dev)
+    # rows of equal length (ELL): y = sum_k vals[:, k] x[cols[:, k]] is plain
+    # gather / multiply / add, which a HIP graph can hold (`_coarse_solve`)
+    width = int(np.diff(E0.indptr).max())
+    cols = np.zeros((E, width), dtype=np.int64)
+    vals = np.zeros((E, width), dtype=np.float64)
+    row = np.repeat(np.arange(E), np.diff(E0.indptr))
+    slot = np.arange(E0.nnz) - np.repeat(E0.indptr[:-1], np.diff(E0.indptr))
+    cols[row, slot] = E0.indices
+    vals[row, slot] = E0.data
+    self.E0_cols = torch.as_tensor(cols, device=dev)
+    self.E0_vals = torch.as_tensor(vals, dtype=dtype, device=dev)
+    self._coarse_graph = None
     # constants are in the kernel of E_0 when nothing pins the pressure
     resid = np.abs(E0 @ np.ones(E)).max() / max(np.abs(E0.diagonal()).max(),
                                                 1e-300)
     self.coarse_singular = bool(resid < 1e-8)
 
+  def coarse_matvec(self, x):
+    return (self.E0_vals * x[self.E0_cols]).sum(dim=1)
+
   def _coarse_solve(self, b):
+    """The coarse solve as ONE graph launch: its few hundred tiny kernels are
+    recorded once (fixed iteration count, fixed buffers) and replayed."""
+    if self._coarse_graph is None:
+      self._coarse_in = torch.zeros_like(b)
+      for _ in range(2):                         # warm-up outside the capture
+        self._coarse_iterate(self._coarse_in)
+      torch.cuda.synchronize()
+      graph = torch.cuda.CUDAGraph()
+      try:
+        with torch.cuda.graph(graph):
+          self._coarse_out = self._coarse_iterate(self._coarse_in)
+        self._coarse_graph = graph
+      except Exception:                  # pylint: disable=broad-except
+        torch.cuda.synchronize()
+        self._coarse_graph = False
+    if self._coarse_graph is False:
+      return self._coarse_iterate(b)
+    self._coarse_in.copy_(b)
+    self._coarse_graph.replay()
+    return self._coarse_out
+
+  def _coarse_iterate(self, b):
     """`coarse_iterations` Jacobi-preconditioned CG iterations on E_0 y = b
     (all on the device, no convergence test: a fixed linear-in-practice map)."""
     if self.coarse_singular:
@@ -190,7 +223,7 @@ class SchwarzPressurePreconditioner:
     rz = torch.dot(r, z)
     tiny = torch.finfo(b.dtype).tiny
     for _ in range(self.coarse_iterations):
-      Ap = torch.mv(self.E0, p)
+      Ap = self.coarse_matvec(p)
       alpha = rz / torch.clamp(torch.dot(p, Ap), min=tiny)
       x = x + alpha * p
       r = r - alpha * Ap
