@@ -630,6 +630,20 @@ int sfem_cg_update_r_mean(void* r, const void* ap, const void* w,
 int sfem_cg_update_xp_mean(void* x, void* p, const void* r, int64_t count,
                            double* scalars, double* sums, double total,
                            int dtype, sfem_stream_t stream);
+/* Element-wise fast diagonalisation solve: for every element e
+ *   z_e = (S_0 (x) .. (x) S_{d-1}) [ w_e .* (S_0 (x) .. (x) S_{d-1})^T r_e ]
+ * r_e / z_e: the Pp^ndim values of element e at r[pel[e][.]] (pel NULL: element
+ * e owns the contiguous range [e Pp^d, (e + 1) Pp^d)), lexicographic, axis 0
+ * slowest; S (num_cases, Pp, Pp) eigenvector matrices (rows = nodes, columns =
+ * modes), cases (ndim, E): which one element e takes along its axis a; w
+ * (E, Pp^d) the (pseudo-)inverted eigenvalues.  The local part of the opt-in
+ * pressure preconditioner (swirl_fem_amd/navier_stokes/
+ * pressure_preconditioner.py) for the reference's hook
+ * navier_stokes/navier_stokes.py:354, :449-452.  Pp <= 10.                   */
+int sfem_fdm_solve(const void* r, void* z, const int64_t* pel, const void* S,
+                   const int32_t* cases, const void* inv_eigenvalues,
+                   int64_t num_elements, int ndim, int Pp, int dtype,
+                   sfem_stream_t stream);
 /* y = a*x + b*y (plain fused vector update used outside the CG core)         */
 int sfem_axpby(double a, const void* x, double b, void* y, int64_t count,
                int dtype, sfem_stream_t stream);

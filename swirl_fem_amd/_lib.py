@@ -123,6 +123,8 @@ SIGNATURES = {
     'sfem_cg_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_cg_update_r_layered': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
                                  c_ptr, c_i32, c_i32, c_ptr],
+    'sfem_fdm_solve': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
+                       c_i32, c_i32, c_ptr],
     'sfem_fold_layers': [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_cg_scalars_n': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr, c_i64,
                           c_ptr],

@@ -650,6 +650,20 @@ def cg_scalars_n(scalars, phase, maxiter, tol, atol, partials, num_partials):
         _ptr(partials), int(num_partials), _stream(dev)), 'sfem_cg_scalars_n')
 
 
+def fdm_solve(r, pel, S, cases, inv_ev, ndim, Pp):
+  """z_e = (S (x) ..) [inv_ev_e .* (S (x) ..)^T r_e] for every element
+  (`sfem_fdm_solve`); `pel` (E, Pp^d) int64 or None for element-contiguous
+  numbering; `cases` (ndim, E) int32."""
+  dev = _dev(r, pel, S, cases, inv_ev)
+  z = torch.empty_like(r)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_fdm_solve(
+        _ptr(r), _ptr(z), _ptr(pel), _ptr(S), _ptr(cases), _ptr(inv_ev),
+        cases.shape[1], int(ndim), int(Pp), _dtype_code(r), _stream(dev)),
+        'sfem_fdm_solve')
+  return z
+
+
 def fold_layers(ext, count, layers):
   """ext[:count] += its layers (in place); returns the view ext[:count]."""
   dev = _dev(ext)

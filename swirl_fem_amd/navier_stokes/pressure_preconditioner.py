@@ -122,12 +122,17 @@ class SchwarzPressurePreconditioner:
     self.S = torch.as_tensor(np.concatenate(S_all), dtype=dtype, device=dev)
     lam = torch.as_tensor(np.concatenate(lam_all), dtype=dtype, device=dev)
     self.case = [torch.as_tensor(c, device=dev) for c in case]
+    self.case32 = torch.stack(self.case).to(torch.int32).contiguous()
     # eigenvalues of the element blocks, pseudo-inverted
     shape = lambda a: [E] + [Pp if b == a else 1 for b in range(d)]
     ev = sum((k2[:, a, None] * lam[self.case[a]]).reshape(shape(a))
              for a in range(d))
     top = ev.reshape(E, -1).max(dim=1).values.reshape([E] + [1] * d)
-    self.inv_ev = torch.where(ev > 1e-10 * top, 1.0 / ev, torch.zeros_like(ev))
+    self.inv_ev = torch.where(ev > 1e-10 * top, 1.0 / ev,
+                              torch.zeros_like(ev)).contiguous()
+    # element e owns the pressure nodes [e n, (e + 1) n): no index array
+    ident = torch.arange(self.pel.numel(), device=dev).reshape(self.pel.shape)
+    self.pel_arg = None if torch.equal(self.pel, ident) else self.pel.contiguous()
     # --- coarse level
     self._build_coarse(q, dtype, dev)
     n1 = round(E ** (1.0 / d))
@@ -247,6 +252,15 @@ class SchwarzPressurePreconditioner:
     return out.movedim(1, 1 + a)
 
   def local_solve(self, r):
+    """One kernel (`sfem_fdm_solve`); `local_solve_torch` is the same with
+    batched matrix products (the test's cross-check)."""
+    from swirl_fem_amd import _ops
+    if self.Pp > 10:
+      return self.local_solve_torch(r)
+    return _ops.fdm_solve(r.contiguous(), self.pel_arg, self.S, self.case32,
+                          self.inv_ev, self.d, self.Pp)
+
+  def local_solve_torch(self, r):
     E, d, Pp = self.pel.shape[0], self.d, self.Pp
     t = r[self.pel].reshape((E,) + (Pp,) * d)
     for a in range(d):
@@ -277,5 +291,8 @@ def make_pressure_preconditioner(sem, name, dt, time_order):
     raise ValueError(f'unknown pressure preconditioner {name!r}')
   key = ('pressure_pc', name, float(dt), int(time_order))
   if key not in sem._cache:
-    sem._cache[key] = SchwarzPressurePreconditioner(sem, dt, time_order)
+    from swirl_fem_amd import switches
+    its = switches.get('SFEM_PC_COARSE_ITERS')
+    sem._cache[key] = SchwarzPressurePreconditioner(
+        sem, dt, time_order, coarse_iterations=int(its) if its else None)
   return sem._cache[key]

@@ -463,7 +463,11 @@ def test_schwarz_pressure_preconditioner():
   r[el] = torch.randn(el.numel(), dtype=p0.dtype, device=DEV, generator=g)
   r[el] -= r[el].mean()
   z = M.local_solve(r)
-  assert float(z.abs().sum() - z[el].abs().sum()) == 0.0
+  assert float((z - M.local_solve_torch(r)).abs().max()) < 1e-12 * float(
+      z.abs().max())
+  outside = z.clone()
+  outside[el] = 0
+  assert float(outside.abs().max()) == 0.0
   Ez = E(z)
   assert float((Ez[el] - Ez[el].mean() - r[el]).abs().max()) < 1e-8 * float(
       r.abs().max())
