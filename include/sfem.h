@@ -644,6 +644,17 @@ int sfem_fdm_solve(const void* r, void* z, const int64_t* pel, const void* S,
                    const int32_t* cases, const void* inv_eigenvalues,
                    int64_t num_elements, int ndim, int Pp, int dtype,
                    sfem_stream_t stream);
+/* x = q(D^-1 A) D^-1 b: `steps` steps of the Chebyshev iteration for the
+ * interval [lmin, lmax] of the Jacobi-scaled sparse matrix A, a FIXED
+ * polynomial (no inner products; linear, symmetric positive definite whenever
+ * lmax bounds the spectrum): the coarse solve of the same preconditioner.
+ * A: n rows of `width` entries, column-major (entry k of row i at
+ * [k * n + i]; unused entries: value 0, any valid column); dinv = 1 / diag(A);
+ * work: 3 n reals.  One launch per step.                                      */
+int sfem_ell_chebyshev(const int32_t* cols, const void* vals, const void* dinv,
+                       const void* b, void* x, void* work, int64_t n,
+                       int width, int steps, double lmin, double lmax,
+                       int dtype, sfem_stream_t stream);
 /* y = a*x + b*y (plain fused vector update used outside the CG core)         */
 int sfem_axpby(double a, const void* x, double b, void* y, int64_t count,
                int dtype, sfem_stream_t stream);

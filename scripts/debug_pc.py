@@ -19,7 +19,7 @@ print('local exact err', float((Ez[el]-Ez[el].mean()-r[el]).abs().max()/r.abs().
 yc=torch.randn(M.pel.shape[0],dtype=p.dtype,device=DEV,generator=g)
 fine=torch.zeros(npr,dtype=p.dtype,device=DEV); fine[M.pel.reshape(-1)]=yc[:,None].expand(-1,M.pel.shape[1]).reshape(-1)
 want=E(fine)[M.pel].sum(dim=1); got=M.coarse_matvec(yc)
-print('coarse op err', float((got-want).abs().max()/want.abs().max()), 'singular', M.coarse_singular, 'iters', M.coarse_iterations)
+print("coarse op err", float((got-want).abs().max()/want.abs().max()), "singular", M.coarse_singular, "iters", M.coarse_iterations, "bounds", M.coarse_bounds)
 yc=yc-yc.mean(); bc=M.coarse_matvec(yc); xc=M._coarse_solve(bc); print('coarse solve err', float((xc-yc).abs().max()/yc.abs().max()))
 b=E(torch.randn(npr,dtype=p.dtype,device=DEV,generator=g))
 P0=ns._NullspaceProjection(sem)

@@ -664,6 +664,22 @@ def fdm_solve(r, pel, S, cases, inv_ev, ndim, Pp):
   return z
 
 
+def ell_chebyshev(cols, vals, dinv, b, steps, lmin, lmax, work=None):
+  """x = Chebyshev polynomial of the Jacobi-scaled ELL matrix applied to b
+  (`sfem_ell_chebyshev`); cols / vals (width, n) int32 / real."""
+  dev = _dev(cols, vals, dinv, b)
+  n = b.numel()
+  x = torch.empty_like(b)
+  if work is None:
+    work = torch.empty(3 * n, dtype=b.dtype, device=b.device)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ell_chebyshev(
+        _ptr(cols), _ptr(vals), _ptr(dinv), _ptr(b), _ptr(x), _ptr(work), n,
+        cols.shape[0], int(steps), float(lmin), float(lmax), _dtype_code(b),
+        _stream(dev)), 'sfem_ell_chebyshev')
+  return x
+
+
 def fold_layers(ext, count, layers):
   """ext[:count] += its layers (in place); returns the view ext[:count]."""
   dev = _dev(ext)

@@ -77,9 +77,89 @@ fdm_solve_kernel(const T* __restrict__ r, T* __restrict__ z,
     z[pel ? pel[base + q] : base + q] = buf[cur][q];
 }
 
+// ---------------------------------------------------------------------------
+// Coarse level of the same preconditioner: a fixed Chebyshev polynomial in the
+// Jacobi-scaled sparse matrix A (rows of equal length, stored column-major:
+// entry k of row i at [k * n + i]) applied to b,  x = q_m(D^-1 A) D^-1 b  with
+// the residual polynomial of the interval [lmin, lmax].  No inner products,
+// one launch per step, exactly linear and symmetric positive definite for any
+// 0 < lmin as long as lmax bounds the spectrum -- what a preconditioner inside
+// CG needs (a truncated inner CG is neither).
+//   d_0 = D^-1 b / theta;  x += d;  r -= A d;
+//   d <- c1 d + c2 D^-1 r   (c1 = rho' rho, c2 = 2 rho' / delta)
+template <typename T>
+__global__ void __launch_bounds__(256)
+cheb_init_kernel(const T* __restrict__ b, const T* __restrict__ dinv,
+                 T* __restrict__ x, T* __restrict__ r, T* __restrict__ d,
+                 T inv_theta, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  x[i] = T(0);
+  r[i] = b[i];
+  d[i] = inv_theta * dinv[i] * b[i];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+cheb_step_kernel(const int32_t* __restrict__ cols, const T* __restrict__ vals,
+                 const T* __restrict__ dinv, const T* __restrict__ d_in,
+                 T* __restrict__ d_out, T* __restrict__ r, T* __restrict__ x,
+                 T c1, T c2, int64_t n, int width) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T ad = T(0);
+  for (int k = 0; k < width; ++k)
+    ad += vals[k * n + i] * d_in[cols[k * n + i]];
+  const T di = d_in[i];
+  const T rn = r[i] - ad;
+  r[i] = rn;
+  x[i] += di;
+  d_out[i] = c1 * di + c2 * dinv[i] * rn;
+}
+
 }  // namespace sfem
 
 using namespace sfem;
+
+extern "C" int sfem_ell_chebyshev(const int32_t* cols, const void* vals,
+                                  const void* dinv, const void* b, void* x,
+                                  void* work, int64_t n, int width, int steps,
+                                  double lmin, double lmax, int dtype,
+                                  sfem_stream_t stream) {
+  SFEM_REQUIRE(n >= 0 && width >= 1 && steps >= 1 && lmin > 0 && lmax > lmin,
+               "sfem_ell_chebyshev: bad sizes or spectrum bounds");
+  if (n == 0) return SFEM_OK;
+  SFEM_REQUIRE(cols && vals && dinv && b && x && work,
+               "sfem_ell_chebyshev: null pointer");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_ell_chebyshev: unknown dtype %d", dtype);
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = as_stream(stream);
+#define SFEM_CHEB(T)                                                          \
+  do {                                                                        \
+    T* r = (T*)work;                                                          \
+    T* d0 = r + n;                                                            \
+    T* d1 = d0 + n;                                                           \
+    hipLaunchKernelGGL(cheb_init_kernel<T>, grid, block, 0, st, (const T*)b,  \
+                       (const T*)dinv, (T*)x, r, d0, (T)(1.0 / theta), n);    \
+    double rho = 1.0 / sigma;                                                 \
+    for (int k = 0; k < steps; ++k) {                                         \
+      const double rho_new = 1.0 / (2.0 * sigma - rho);                       \
+      hipLaunchKernelGGL(cheb_step_kernel<T>, grid, block, 0, st, cols,       \
+                         (const T*)vals, (const T*)dinv, (k & 1) ? d1 : d0,   \
+                         (k & 1) ? d0 : d1, r, (T*)x, (T)(rho_new * rho),     \
+                         (T)(2.0 * rho_new / delta), n, width);               \
+      rho = rho_new;                                                          \
+    }                                                                         \
+  } while (0)
+  if (dtype == SFEM_F64) SFEM_CHEB(double);
+  else SFEM_CHEB(float);
+#undef SFEM_CHEB
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
 
 extern "C" int sfem_fdm_solve(const void* r, void* z, const int64_t* pel,
                               const void* S, const int32_t* cases,

@@ -27,7 +27,9 @@ tolerance, the default stays the reference's:
 * coarse part: R_0 sums a vector over each element (piecewise constants),
   E_0 = R_0 E R_0^T is assembled exactly from the elements' boundary fluxes
   int_e d(phi_n)/dx_c (sparse, 27 entries per row on a structured mesh) and
-  solved by a fixed number of Jacobi-preconditioned CG iterations;
+  applied through a fixed Chebyshev polynomial of the Jacobi-scaled E_0
+  (`sfem_ell_chebyshev`: linear and symmetric, which a truncated inner CG is
+  not; spectrum bounds by Lanczos at setup);
 * P: the reference's nullspace projection.
 """
 
@@ -64,7 +66,8 @@ def _centre_cofactors(xe, P, d):
 class SchwarzPressurePreconditioner:
   """`z = M^-1 r` for `cg(E, b, M=...)`; see the module docstring."""
 
-  def __init__(self, sem, dt, time_order, coarse_iterations=None):
+  def __init__(self, sem, dt, time_order, coarse_iterations=None,
+               coarse_solver='chebyshev'):
     self.sem = sem
     vmesh = sem.velocity.mesh
     pmesh = sem.pressure.pspace.mesh
@@ -135,9 +138,13 @@ class SchwarzPressurePreconditioner:
     self.pel_arg = None if torch.equal(self.pel, ident) else self.pel.contiguous()
     # --- coarse level
     self._build_coarse(q, dtype, dev)
-    n1 = round(E ** (1.0 / d))
+    # steps for a residual reduction of ~ 1e-2 on [lmin, lmax]:
+    # sqrt(kappa) ln(2 / eps) / 2
+    lmin, lmax = self.coarse_bounds
+    self.coarse_solver = coarse_solver
     self.coarse_iterations = (int(coarse_iterations) if coarse_iterations
-                              else max(20, 3 * n1))
+                              else max(8, int(np.ceil(
+                                  np.sqrt(lmax / lmin) * np.log(200.0) / 2))))
     self.project = ns._NullspaceProjection(sem)
 
   # ------------------------------------------------------------- coarse level
@@ -184,16 +191,54 @@ class SchwarzPressurePreconditioner:
     vals[row, slot] = E0.data
     self.E0_cols = torch.as_tensor(cols, device=dev)
     self.E0_vals = torch.as_tensor(vals, dtype=dtype, device=dev)
+    # column-major copies for the Chebyshev kernel (`sfem_ell_chebyshev`)
+    self.E0_cols_t = self.E0_cols.t().to(torch.int32).contiguous()
+    self.E0_vals_t = self.E0_vals.t().contiguous()
     self._coarse_graph = None
     # constants are in the kernel of E_0 when nothing pins the pressure
     resid = np.abs(E0 @ np.ones(E)).max() / max(np.abs(E0.diagonal()).max(),
                                                 1e-300)
     self.coarse_singular = bool(resid < 1e-8)
+    # spectrum of D^-1 E_0 on the complement of the constants: Lanczos (host,
+    # SciPy, setup only) for the two ends; the Chebyshev polynomial is built
+    # for [lmin, lmax] and stays positive definite as long as lmax is a bound
+    import scipy.sparse.linalg as spla
+    dm = 1.0 / np.sqrt(E0.diagonal())
+    Ssym = sp.diags(dm) @ E0 @ sp.diags(dm)
+    lmax = float(spla.eigsh(Ssym, k=1, which='LA', tol=1e-3,
+                            return_eigenvectors=False)[0])
+    # smallest non-zero eigenvalue: a few Lanczos steps on the deflated
+    # operator (shift-invert would need a factorisation of the coarse matrix)
+    k = 2 if self.coarse_singular else 1
+    try:
+      low = spla.eigsh(Ssym, k=k, which='SA', tol=1e-2, maxiter=20 * E,
+                       return_eigenvectors=False)
+      lmin = float(np.sort(low)[-1])
+    except spla.ArpackNoConvergence as exc:
+      got = np.sort(exc.eigenvalues)
+      lmin = float(got[-1]) if len(got) >= k else lmax / (4.0 * E ** (2.0 / d))
+    self.coarse_bounds = (0.8 * max(lmin, 1e-12 * lmax), 1.05 * lmax)
 
   def coarse_matvec(self, x):
     return (self.E0_vals * x[self.E0_cols]).sum(dim=1)
 
   def _coarse_solve(self, b):
+    """E_0^+ b to the accuracy a preconditioner needs: a fixed Chebyshev
+    polynomial of the Jacobi-scaled coarse matrix (`sfem_ell_chebyshev`: one
+    small launch per step, no inner products, exactly linear and symmetric);
+    `coarse_solver = 'cg'` keeps the truncated CG of the first version."""
+    if self.coarse_solver == 'cg':
+      return self._coarse_solve_cg(b)
+    from swirl_fem_amd import _ops
+    if self.coarse_singular:
+      b = b - b.mean()
+    lmin, lmax = self.coarse_bounds
+    x = _ops.ell_chebyshev(self.E0_cols_t, self.E0_vals_t,
+                           1.0 / self.coarse_diag, b.contiguous(),
+                           self.coarse_iterations, lmin, lmax)
+    return x - x.mean() if self.coarse_singular else x
+
+  def _coarse_solve_cg(self, b):
     """The coarse solve as ONE graph launch: its few hundred tiny kernels are
     recorded once (fixed iteration count, fixed buffers) and replayed."""
     if self._coarse_graph is None:

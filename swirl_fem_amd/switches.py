@@ -97,9 +97,9 @@ SWITCHES = {
                          'constant coarse level, '
                          'navier_stokes/pressure_preconditioner.py)'),
     'SFEM_PC_COARSE_ITERS': (None, 'navier_stokes/pressure_preconditioner.py',
-                             'CG iterations of the coarse solve inside the '
-                             "'schwarz' preconditioner (default: 3 x elements "
-                             'per direction, at least 20)'),
+                             'Chebyshev steps of the coarse solve inside the '
+                             "'schwarz' preconditioner (default: from the "
+                             'spectrum bounds, ~ sqrt(kappa) ln(200) / 2)'),
     'SFEM_PRESSURE_PROJECTION': ('0', 'navier_stokes/navier_stokes.py',
                                  'number of earlier pressure increments the '
                                  'steppers project the next pressure solve '
