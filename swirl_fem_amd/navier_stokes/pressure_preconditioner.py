@@ -319,10 +319,14 @@ class SchwarzPressurePreconditioner:
 
   def __call__(self, r):
     z = self.local_solve(r)
-    rc = r[self.pel].sum(dim=1)
-    yc = self._coarse_solve(rc)
-    z = z.index_add(0, self.pel.reshape(-1),
-                    yc[:, None].expand(-1, self.pel.shape[1]).reshape(-1))
+    E, n = self.pel.shape
+    if self.pel_arg is None:           # element e owns [e n, (e + 1) n)
+      yc = self._coarse_solve(r.view(E, n).sum(dim=1))
+      z.view(E, n).add_(yc[:, None])
+    else:
+      yc = self._coarse_solve(r[self.pel].sum(dim=1))
+      z = z.index_add(0, self.pel.reshape(-1),
+                      yc[:, None].expand(-1, n).reshape(-1))
     return self.project(z)
 
 
