@@ -19,62 +19,82 @@ namespace sfem {
 
 constexpr int FDM_MAX_P = 10;
 
-template <typename T>
+// PP = Pp and D = ndim at compile time: the index arithmetic of the mode
+// products (divisions by powers of Pp) folds into shifts / multiplies and the
+// inner sums unroll (a run-time Pp measured 2.16 ms at 64^3 elements, p = 7:
+// 5 x the kernel's memory time).
+template <typename T, int D, int PP>
 __global__ void __launch_bounds__(64)
 fdm_solve_kernel(const T* __restrict__ r, T* __restrict__ z,
                  const int64_t* __restrict__ pel, const T* __restrict__ S,
                  const int32_t* __restrict__ cases, const T* __restrict__ w,
-                 int64_t num_elements, int d, int Pp) {
-  __shared__ T buf[2][FDM_MAX_P * FDM_MAX_P * FDM_MAX_P];
-  __shared__ T mat[3][FDM_MAX_P * FDM_MAX_P];
+                 int64_t num_elements) {
+  constexpr int N = D == 3 ? PP * PP * PP : (D == 2 ? PP * PP : PP);
+  __shared__ T buf[2][N];
+  __shared__ T mat[D][PP * PP];
   const int64_t e = blockIdx.x;
   const int lane = threadIdx.x;
-  int n = 1;
-  for (int a = 0; a < d; ++a) n *= Pp;
-  const int pp2 = Pp * Pp;
-  for (int a = 0; a < d; ++a) {
-    const T* Sa = S + (int64_t)cases[a * num_elements + e] * pp2;
-    for (int q = lane; q < pp2; q += 64) mat[a][q] = Sa[q];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const T* Sa = S + (int64_t)cases[a * num_elements + e] * (PP * PP);
+    for (int q = lane; q < PP * PP; q += 64) mat[a][q] = Sa[q];
   }
-  const int64_t base = e * n;
-  for (int q = lane; q < n; q += 64)
+  const int64_t base = e * N;
+  for (int q = lane; q < N; q += 64)
     buf[0][q] = r[pel ? pel[base + q] : base + q];
   __syncthreads();
   int cur = 0;
-  // forward: t_m = sum_i S[i][m] r_i along every axis
-  for (int a = 0; a < d; ++a) {
-    int stride = 1;
-    for (int b = a + 1; b < d; ++b) stride *= Pp;
-    for (int o = lane; o < n; o += 64) {
-      const int post = o % stride, m = (o / stride) % Pp;
-      const int pre = o / (stride * Pp);
-      const T* in = &buf[cur][pre * Pp * stride + post];
-      T acc = T(0);
-      for (int i = 0; i < Pp; ++i) acc += mat[a][i * Pp + m] * in[i * stride];
-      buf[cur ^ 1][o] = acc;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      constexpr int P2 = PP * PP;
+      const int stride = a == D - 1 ? 1 : (a == D - 2 ? PP : P2);
+      for (int o = lane; o < N; o += 64) {
+        const int post = o % stride, m = (o / stride) % PP;
+        const int pre = o / (stride * PP);
+        const T* in = &buf[cur][pre * PP * stride + post];
+        T acc = T(0);
+        if (pass == 0) {      // t_m = sum_i S[i][m] r_i
+#pragma unroll
+          for (int i = 0; i < PP; ++i)
+            acc += mat[a][i * PP + m] * in[i * stride];
+        } else {              // z_i = sum_m S[i][m] t_m  (m plays i here)
+#pragma unroll
+          for (int i = 0; i < PP; ++i)
+            acc += mat[a][m * PP + i] * in[i * stride];
+        }
+        buf[cur ^ 1][o] = acc;
+      }
+      cur ^= 1;
+      __syncthreads();
     }
-    cur ^= 1;
-    __syncthreads();
-  }
-  for (int q = lane; q < n; q += 64) buf[cur][q] *= w[base + q];
-  __syncthreads();
-  // backward: z_i = sum_m S[i][m] t_m
-  for (int a = 0; a < d; ++a) {
-    int stride = 1;
-    for (int b = a + 1; b < d; ++b) stride *= Pp;
-    for (int o = lane; o < n; o += 64) {
-      const int post = o % stride, i = (o / stride) % Pp;
-      const int pre = o / (stride * Pp);
-      const T* in = &buf[cur][pre * Pp * stride + post];
-      T acc = T(0);
-      for (int m = 0; m < Pp; ++m) acc += mat[a][i * Pp + m] * in[m * stride];
-      buf[cur ^ 1][o] = acc;
+    if (pass == 0) {
+      for (int q = lane; q < N; q += 64) buf[cur][q] *= w[base + q];
+      __syncthreads();
     }
-    cur ^= 1;
-    __syncthreads();
   }
-  for (int q = lane; q < n; q += 64)
+  for (int q = lane; q < N; q += 64)
     z[pel ? pel[base + q] : base + q] = buf[cur][q];
+}
+
+template <typename T, int D>
+static int launch_fdm(int Pp, dim3 grid, hipStream_t st, const T* r, T* z,
+                      const int64_t* pel, const T* S, const int32_t* cases,
+                      const T* w, int64_t E) {
+#define SFEM_FDM_CASE(PPV)                                                    \
+  case PPV:                                                                   \
+    hipLaunchKernelGGL((fdm_solve_kernel<T, D, PPV>), grid, dim3(64), 0, st,  \
+                       r, z, pel, S, cases, w, E);                            \
+    return SFEM_OK;
+  switch (Pp) {
+    SFEM_FDM_CASE(1) SFEM_FDM_CASE(2) SFEM_FDM_CASE(3) SFEM_FDM_CASE(4)
+    SFEM_FDM_CASE(5) SFEM_FDM_CASE(6) SFEM_FDM_CASE(7) SFEM_FDM_CASE(8)
+    SFEM_FDM_CASE(9) SFEM_FDM_CASE(10)
+  }
+#undef SFEM_FDM_CASE
+  set_error("sfem_fdm_solve: Pp=%d outside 1..%d", Pp, FDM_MAX_P);
+  return SFEM_EUNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------
@@ -173,21 +193,26 @@ extern "C" int sfem_fdm_solve(const void* r, void* z, const int64_t* pel,
   SFEM_REQUIRE(r && z && S && cases && inv_eigenvalues,
                "sfem_fdm_solve: null pointer");
   SFEM_REQUIRE(num_elements <= 0x7fffffff, "sfem_fdm_solve: too many elements");
-  const dim3 grid((unsigned)num_elements), block(64);
+  const dim3 grid((unsigned)num_elements);
+  hipStream_t st = as_stream(stream);
+  int rc;
+#define SFEM_FDM_DIM(T, DV)                                                   \
+  launch_fdm<T, DV>(Pp, grid, st, (const T*)r, (T*)z, pel, (const T*)S,       \
+                    cases, (const T*)inv_eigenvalues, num_elements)
   if (dtype == SFEM_F64)
-    hipLaunchKernelGGL(fdm_solve_kernel<double>, grid, block, 0,
-                       as_stream(stream), (const double*)r, (double*)z, pel,
-                       (const double*)S, cases, (const double*)inv_eigenvalues,
-                       num_elements, ndim, Pp);
+    rc = ndim == 3 ? SFEM_FDM_DIM(double, 3)
+                   : (ndim == 2 ? SFEM_FDM_DIM(double, 2)
+                                : SFEM_FDM_DIM(double, 1));
   else if (dtype == SFEM_F32)
-    hipLaunchKernelGGL(fdm_solve_kernel<float>, grid, block, 0,
-                       as_stream(stream), (const float*)r, (float*)z, pel,
-                       (const float*)S, cases, (const float*)inv_eigenvalues,
-                       num_elements, ndim, Pp);
+    rc = ndim == 3 ? SFEM_FDM_DIM(float, 3)
+                   : (ndim == 2 ? SFEM_FDM_DIM(float, 2)
+                                : SFEM_FDM_DIM(float, 1));
   else {
     set_error("sfem_fdm_solve: unknown dtype %d", dtype);
     return SFEM_EINVAL;
   }
+#undef SFEM_FDM_DIM
+  if (rc != SFEM_OK) return rc;
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }
