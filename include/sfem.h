@@ -572,6 +572,9 @@ int sfem_cg_update_xp(void* x, void* p, const void* z, int64_t count,
  * atomically; `*num_rr` receives the number of workgroups (<= rr_capacity, the
  * launch is sized to fit).  A CG iteration built from these and the layered
  * apply is bitwise reproducible from run to run.                              */
+/* `partials` must have room for num_partials + SFEM_FOLD_GROUPS doubles: long
+ * sums are taken in two fixed-order stages through the scratch behind them.   */
+#define SFEM_FOLD_GROUPS 256
 int sfem_cg_scalars_n(double* scalars, int phase, double maxiter, double tol,
                       double atol, double* partials, int64_t num_partials,
                       sfem_stream_t stream);

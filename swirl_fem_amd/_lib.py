@@ -25,6 +25,7 @@ CG_STATUS = {0: 'running', 1: 'converged', 2: 'maxiter', 3: 'breakdown_pAp',
 SFEM_DOT_SLOTS = 1024
 SFEM_CG_MEAN_SUMS = 256    # 2 parities x (64 sums of 1.r + 64 sums of w.r)
 SFEM_MAX_LAYERS = 15
+SFEM_FOLD_GROUPS = 256
 SFEM_CG_LAZY_MAX = 8
 
 c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,

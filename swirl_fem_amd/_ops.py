@@ -591,6 +591,7 @@ def helmholtz_apply_layered(u, ext, enc, parts, host, ndim, P, lambda0,
   host = {k: _host(v, u.dtype) for k, v in host.items()}
   waves = (layered_dot_waves(parts, P, enc.shape[0])
            if per_wave and dot_out is not None else None)
+  # (the caller's buffer may carry scratch behind the slots)
   if waves is not None and sum(waves) > dot_out.numel():
     raise ValueError(f'{sum(waves)} waves but {dot_out.numel()} dot slots')
   at = 0

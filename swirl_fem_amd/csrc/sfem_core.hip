@@ -1077,6 +1077,18 @@ __device__ __forceinline__ double strided_sum(const double* __restrict__ partial
   return v;
 }
 
+// Stage one of a long fixed-order sum: workgroup g adds up its contiguous
+// chunk of `partials` and stores the result at scratch[g].
+__global__ void __launch_bounds__(256)
+fold_partials_kernel(const double* __restrict__ partials, int64_t n,
+                     int64_t chunk, double* __restrict__ scratch) {
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  const int64_t len = n - lo < chunk ? n - lo : chunk;
+  const double total = block_sum(len > 0 ? strided_sum(partials + lo, len)
+                                         : 0.0);
+  if (threadIdx.x == 0) scratch[blockIdx.x] = total;
+}
+
 __global__ void __launch_bounds__(1024)
 cg_scalar_kernel(double* scalars, int phase, double maxiter, double tol,
                  double atol, double* partials, int64_t num_partials,
@@ -1753,10 +1765,20 @@ int sfem_cg_scalars_n(double* scalars, int phase, double maxiter, double tol,
   SFEM_REQUIRE(scalars && partials && num_partials >= 1 &&
                    (phase == 3 || phase == 4 || phase == 5 || phase == 8),
                "sfem_cg_scalars_n: phases 3, 4, 5, 8 over stored partial sums");
-  // one workgroup sums tens of thousands of stored values: 1024 threads keep
-  // its loads few and independent (32 per thread at config 2)
-  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1),
-                     dim3(num_partials > 4096 ? 1024 : 256), 0,
+  // long sums in two fixed-order stages: SFEM_FOLD_GROUPS workgroups reduce
+  // contiguous chunks into the scratch behind the partial sums, the scalar
+  // kernel adds those up (one workgroup over 786 k values -- p = 11, three
+  // waves per element -- took 170 us)
+  if (num_partials > 4096) {
+    const int64_t chunk = (num_partials + SFEM_FOLD_GROUPS - 1) /
+                          SFEM_FOLD_GROUPS;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(SFEM_FOLD_GROUPS), dim3(256),
+                       0, as_stream(stream), partials, num_partials, chunk,
+                       partials + num_partials);
+    partials += num_partials;
+    num_partials = SFEM_FOLD_GROUPS;
+  }
+  hipLaunchKernelGGL(cg_scalar_kernel, dim3(1), dim3(256), 0,
                      as_stream(stream), scalars, phase, maxiter, tol, atol,
                      partials, num_partials, true);
   SFEM_LAUNCH_CHECK();

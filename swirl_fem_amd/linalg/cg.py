@@ -193,9 +193,12 @@ class CGRunner:
     # from run to run; costs one more scalar launch per iteration
     self.det = None
     if self.layered is not None and switches.get('SFEM_DETERMINISTIC') != '0':
-      self.det = (torch.zeros(A.layered_dot_slots(), dtype=torch.float64,
+      # (+ SFEM_FOLD_GROUPS: scratch of the two-stage sums behind the slots)
+      pad = _lib.SFEM_FOLD_GROUPS
+      self.det = (torch.zeros(A.layered_dot_slots() + pad, dtype=torch.float64,
                               device=device),
-                  torch.zeros(RR_PARTIALS, dtype=torch.float64, device=device))
+                  torch.zeros(RR_PARTIALS + pad, dtype=torch.float64,
+                              device=device))
       self._reproducible_start(b, z)
     # Lazy solution update (`sfem_cg_update_xp_lazy`): x is touched every m-th
     # iteration only, the directions in between wait in a ring -- bitwise the
@@ -316,7 +319,8 @@ class CGRunner:
     if self.fused_dot and self.det is not None:
       Ap = A.apply_layered_with_dot(self.p, self.det[0], per_wave=True)
       _ops.cg_scalars_n(s.t, 5, self.maxiter, self.tol, self.atol,
-                        self.det[0], self.det[0].numel())
+                        self.det[0],
+                        self.det[0].numel() - _lib.SFEM_FOLD_GROUPS)
     elif self.fused_dot:
       Ap = (A.apply_layered_with_dot(self.p, s.partials)
             if self.layered is not None
@@ -355,8 +359,9 @@ class CGRunner:
       self.issued += 1
       return
     if self.layered is not None and self.det is not None and self.fuse_rr:
-      n = _ops.cg_update_r_layered_det(self.r, Ap, self.layered.layers, s.t,
-                                       self.det[1])
+      n = _ops.cg_update_r_layered_det(
+          self.r, Ap, self.layered.layers, s.t,
+          self.det[1][:RR_PARTIALS])
       _ops.cg_scalars_n(s.t, 8, self.maxiter, self.tol, self.atol,
                         self.det[1], n)
     elif self.layered is not None:
