@@ -337,6 +337,14 @@ int sfem_facet_table_build(const int32_t* elements, const uint8_t* dirichlet,
                            uint8_t* ok, int64_t num_elements,
                            int64_t num_nodes, int P, sfem_stream_t stream);
 
+/* Self-test of an assumption of the facet / chain kernels: they read their
+ * by-value matrix argument through the kernarg segment at the offset the
+ * current code-object ABI places it.  Launches probe kernels that OR a
+ * non-zero value into *bad (a zeroed device int32) if the bytes seen there
+ * differ from the argument.  The Python layer runs it once per process before
+ * the first facet launch and refuses to continue on a mismatch.              */
+int sfem_kernarg_selftest(int32_t* bad, sfem_stream_t stream);
+
 /* geo_elem (E, 24) of affine elements -> geo_const (E, 8) =
  * { G00, G01, G02, G11, G12, G22, detJ, box } with G = detJ J^-1 J^-T (no
  * quadrature weight) and box = 1 when |G01|, |G02|, |G12| <= box_tol *

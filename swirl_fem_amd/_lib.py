@@ -124,6 +124,7 @@ SIGNATURES = {
     'sfem_cg_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_cg_update_r_layered': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
                                  c_ptr, c_i32, c_i32, c_ptr],
+    'sfem_kernarg_selftest': [c_ptr, c_ptr],
     'sfem_fdm_solve': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                        c_i32, c_i32, c_ptr],
     'sfem_ell_chebyshev': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,

@@ -379,11 +379,33 @@ def helmholtz_setup_multilinear(elem_coords, ndim, P):
   return geo_elem
 
 
+_KERNARG_CHECKED = set()
+
+
+def kernarg_selftest(dev):
+  """Once per process and device: the facet kernels' view of their matrix
+  argument through the kernarg segment is what was passed
+  (`sfem_kernarg_selftest`); raises otherwise."""
+  if dev in _KERNARG_CHECKED:
+    return
+  bad = torch.zeros(1, dtype=torch.int32, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_kernarg_selftest(_ptr(bad), _stream(dev)),
+               'sfem_kernarg_selftest')
+  if int(bad.item()) != 0:
+    raise _lib.SfemError(
+        'the kernel-argument layout differs from what the facet kernels '
+        f'assume (probe flags {int(bad.item())}): rebuild libsfem_hip.so with '
+        'the toolchain it was written for (FacetKernarg::MAT_OFF)')
+  _KERNARG_CHECKED.add(dev)
+
+
 def facet_table(elements, dirichlet_u8, multiplicity, P):
   """Compact connectivity (`sfem_facet_table_build`): `(E, 27, 4)` int32
   table and the `(E,)` bool mask of the elements it describes exactly."""
   elements = _idx(elements)
   dev = _dev(elements, dirichlet_u8, multiplicity)
+  kernarg_selftest(dev)      # every facet launch starts from a table
   E = elements.shape[0]
   tab = torch.empty((E, 27, 4), dtype=torch.int32, device=dev)
   ok = torch.empty((E,), dtype=torch.uint8, device=dev)

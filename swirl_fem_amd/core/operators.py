@@ -807,11 +807,26 @@ def supports_fused_stokes(vspace, pspace) -> str | None:
     rounding = 32 * torch.finfo(jv.dtype).eps * P * P * max(xmax / h, 1.0)
   else:
     rounding = 0.0
-  tol = max(1e-10 if jv.dtype == torch.float64 else 1e-4, rounding)
+  tight = 1e-10 if jv.dtype == torch.float64 else 1e-4
+  # ... which excuses only elements that ARE images of one premesh in both
+  # spaces (affine / multilinear: exact up to that rounding); elements with
+  # nodes of their own (curved) must agree tightly, or a pressure geometry that
+  # really differs would slip through on fine fp32 meshes
+  kind = _cached_geometry_kind(vspace)[sample]
+  tol = torch.where(kind != _GEO_POINT, max(tight, rounding), tight).to(
+      jv.dtype)
   if jv.shape != jp.shape or not bool(
-      ((jv - jp).abs() <= tol * jv.abs().amax()).all()):
+      ((jv - jp).abs() <= tol[:, None] * jv.abs().amax()).all()):
     return 'velocity and pressure spaces carry different geometry'
   return None
+
+
+def _cached_geometry_kind(fespace):
+  """`classify_geometry(fespace)[0]`, kept in the space's cache."""
+  cache = fespace._cache
+  if 'geometry_kind' not in cache:
+    cache['geometry_kind'] = classify_geometry(fespace)[0]
+  return cache['geometry_kind']
 
 
 def _sample_jacdets(space, elements):

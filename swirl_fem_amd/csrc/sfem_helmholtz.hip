@@ -341,6 +341,33 @@ static int check_geometry(const char* who, int geo_mode, const void* geo,
   return SFEM_OK;
 }
 
+// The facet / chain kernels read their matrix argument through the kernarg
+// segment at FacetKernarg::MAT_OFF = align(sizeof(params)) -- the offset the
+// code-object ABI gives the second by-value argument today.  Nothing in the
+// language promises it: this probe compares those bytes with the argument
+// itself, so that a compiler or ABI change fails loudly instead of feeding the
+// kernels garbage matrices.
+template <typename PRM, typename MAT>
+__global__ void kernarg_probe_kernel(PRM prm, MAT mat, int32_t* bad) {
+  const char* seen = kernarg_bytes() + FacetKernarg<PRM, MAT>::MAT_OFF;
+  const char* want = reinterpret_cast<const char*>(&mat);
+  for (size_t q = threadIdx.x; q < sizeof(MAT); q += blockDim.x)
+    if (seen[q] != want[q]) atomicOr(bad, 1);
+  if (threadIdx.x == 0 && prm.ncomp != 12345) atomicOr(bad, 2);
+}
+
+template <typename PRM, typename MAT>
+static void launch_kernarg_probe(int32_t* bad, hipStream_t st) {
+  PRM prm{};
+  prm.ncomp = 12345;
+  MAT mat;
+  unsigned char* bytes = reinterpret_cast<unsigned char*>(&mat);
+  for (size_t q = 0; q < sizeof(MAT); ++q)
+    bytes[q] = (unsigned char)(37 * q + 11);
+  hipLaunchKernelGGL((kernarg_probe_kernel<PRM, MAT>), dim3(1), dim3(64), 0,
+                     st, prm, mat, bad);
+}
+
 }  // namespace sfem
 
 using namespace sfem;
@@ -500,6 +527,17 @@ int sfem_helmholtz_apply(const sfem_helmholtz_args* a, sfem_stream_t stream) {
                "sfem_helmholtz_apply: layered assembly needs a facet table");
   if (a->dtype == SFEM_F64) return run_helmholtz<double>(c, as_stream(stream));
   return run_helmholtz<float>(c, as_stream(stream));
+}
+
+int sfem_kernarg_selftest(int32_t* bad, sfem_stream_t stream) {
+  SFEM_REQUIRE(bad, "sfem_kernarg_selftest: null pointer");
+  hipStream_t st = as_stream(stream);
+  launch_kernarg_probe<FacetParams<double>, SMat<double, 8>>(bad, st);
+  launch_kernarg_probe<FacetParams<double>, DMat<double, 8>>(bad, st);
+  launch_kernarg_probe<FacetParams<float>, DMat<float, 12>>(bad, st);
+  launch_kernarg_probe<FacetParams<float>, SMat<float, 12>>(bad, st);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
 }
 
 int sfem_facet_table_build(const int32_t* elements, const uint8_t* dirichlet,

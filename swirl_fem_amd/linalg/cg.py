@@ -219,6 +219,7 @@ class CGRunner:
       self._shape = tuple(self.r.shape)
     self.issued = 0
     self._graph = None
+    self._capture_failed = False
 
   def _reproducible_start(self, b, z):
     """b.b and gamma_0 = r.z again, as tree reductions without atomics (the
@@ -269,8 +270,11 @@ class CGRunner:
       maxiter = 10 * sum(l.numel() for l in theirs)
     if maxiter != self.maxiter:
       return False
+    # (component-major and row-major (N, d) fields have the same shape: the
+    # strides tell them apart; `restart` repacks a dense b of another layout)
     return all(isinstance(t, torch.Tensor) and t.shape == m.shape and
-               t.dtype == m.dtype and t.device == m.device
+               t.dtype == m.dtype and t.device == m.device and
+               (t.stride() == m.stride() or t.is_contiguous())
                for m, t in zip(mine, theirs))
 
   def restart(self, b, x0=None):
@@ -437,13 +441,26 @@ class CGRunner:
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     issued = self.issued
+    # The cyclic collector must not run while the stream is capturing: an
+    # older solver state that sits in a reference cycle (stepper -> cache ->
+    # runner -> operator -> stepper) owns a graph and its memory pool, and
+    # freeing those in the middle of a capture aborts the process.  Collect
+    # first, then keep the collector off until the capture has ended.
+    import gc
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
     try:
       with torch.cuda.graph(graph):
         self._step_eager()
     except Exception:              # pylint: disable=broad-except
       torch.cuda.synchronize()
       self.issued = issued
+      self._capture_failed = True  # (a kept runner does not try again)
       return False
+    finally:
+      if was_enabled:
+        gc.enable()
     self.issued = issued           # capture records, it does not execute
     self._graph = graph
     return True
@@ -517,6 +534,7 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
            dot_fn is None and reduce_fn is None and interface is None)
   run = workspace.get(key) if reuse else None
   if run is not None and run.matches(b, tol, atol, maxiter):
+    workspace[key] = workspace.pop(key)      # most recently used goes last
     run.restart(b, x0)
   else:
     run = CGRunner(A, b, x0, tol=tol, atol=atol, maxiter=maxiter, M=M,
@@ -529,7 +547,7 @@ def cg(A, b, x0=None, *, tol=1e-5, atol=0.0, maxiter=None, M=None,
       while len(workspace) > MAX_KEPT_RUNNERS:
         workspace.pop(next(iter(workspace)))
   if (graph and dot_fn is None and run.maxiter > 2 and run._graph is None and
-      not run.done()):
+      not run._capture_failed and not run.done()):
     run.capture()
   while run.issued < run.maxiter:
     for _ in range(min(check_every, run.maxiter - run.issued)):

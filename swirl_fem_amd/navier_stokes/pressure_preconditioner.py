@@ -247,6 +247,10 @@ class SchwarzPressurePreconditioner:
         self._coarse_iterate(self._coarse_in)
       torch.cuda.synchronize()
       graph = torch.cuda.CUDAGraph()
+      import gc                  # (no collection inside a capture: cg.capture)
+      gc.collect()
+      was_enabled = gc.isenabled()
+      gc.disable()
       try:
         with torch.cuda.graph(graph):
           self._coarse_out = self._coarse_iterate(self._coarse_in)
@@ -254,6 +258,9 @@ class SchwarzPressurePreconditioner:
       except Exception:                  # pylint: disable=broad-except
         torch.cuda.synchronize()
         self._coarse_graph = False
+      finally:
+        if was_enabled:
+          gc.enable()
     if self._coarse_graph is False:
       return self._coarse_iterate(b)
     self._coarse_in.copy_(b)

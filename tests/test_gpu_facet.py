@@ -653,3 +653,18 @@ def test_cg_with_layered_assembly(dtype, monkeypatch):
   xm_a, im_a = cg(op_a.linear_operator(0.0, 1.0), bd, tol=tol, M=M)
   assert abs(im['num_iterations'] - im_a['num_iterations']) <= slack
   assert relerr(xm, xm_a.double().cpu().numpy()) < (1e-9 if f64 else 2e-3)
+
+
+def test_kernarg_layout_selftest():
+  """The facet / chain kernels read their matrix through the kernarg segment
+  at a hand-computed offset (`FacetKernarg::MAT_OFF`); the library can check
+  that assumption on the device and the Python layer does so before the first
+  facet launch."""
+  from swirl_fem_amd import _ops
+  _ops._KERNARG_CHECKED.clear()
+  _ops.kernarg_selftest(torch.device(DEV))
+  assert torch.device(DEV) in _ops._KERNARG_CHECKED
+  bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+  rc = _lib.load().sfem_kernarg_selftest(_ops._ptr(bad), _ops._stream(
+      torch.device(DEV)))
+  assert rc == 0 and int(bad.item()) == 0
