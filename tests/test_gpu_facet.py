@@ -637,8 +637,9 @@ def test_cg_with_layered_assembly(dtype, monkeypatch):
   assert CGRunner(A, bd, tol=tol).det is None
   xn, i_n = cg(A, bd, tol=tol)
   monkeypatch.delenv('SFEM_DETERMINISTIC')
+  # (two solves to tol = 1e-10 that may stop one iteration apart)
   close = lambda a, c: float((a - c).abs().max()) <= (
-      1e-11 if f64 else 1e-4) * float(c.abs().max())
+      1e-8 if f64 else 2e-3) * float(c.abs().max())
   assert close(xn, x1) and abs(i_n['num_iterations'] -
                                i1['num_iterations']) <= 1
   slack = 1 if f64 else 3      # 268 iterations: the stop test can flip by one
