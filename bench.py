@@ -648,6 +648,17 @@ def rank_main(args, world, rank, device):
                 'cleared; r -= alpha Ap adds the layers up' % (
                     len(layered.layers), layered.written - N_local, N_local)),
             'switches': switches.active(),
+            'solver': {
+                'lazy_x': (None if getattr(run, 'lazy', None) is None
+                           else 'x takes its terms every %d-th iteration '
+                                '(bitwise the same x; any %d consecutive '
+                                'iterations hold exactly one such update per '
+                                '%d)' % ((run.lazy[0].shape[0],) * 3)),
+                'inner_products': ('stored partial sums added in a fixed '
+                                   'order (bitwise reproducible solve)'
+                                   if getattr(run, 'det', None) is not None
+                                   else 'atomically accumulated partial sums'),
+            },
             'geometry': ('%s: %d affine + %d multilinear elements (factors '
                          'evaluated in registers), %d with 6 stored factors '
                          'per point' % (args.geometry, op.num_affine,

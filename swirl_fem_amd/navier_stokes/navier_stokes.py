@@ -792,7 +792,8 @@ class StokesSEM:
                       M=pressure_preconditioner, tol=tol, atol=atol,
                       # (a caller's preconditioner may do things a recorded
                       # iteration cannot hold: sparse products, host logic)
-                      graph=small(rhs) and default_projection,
+                      graph=small(rhs) and (default_projection or getattr(
+                          pressure_preconditioner, 'capturable', False)),
                       reduce_fn=self._reduce_fn(),
                       **(keep('E', float(dt), int(time_order))
                          if default_projection and small(rhs) else {}))

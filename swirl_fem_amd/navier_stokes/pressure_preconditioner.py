@@ -41,6 +41,9 @@ import torch
 from swirl_fem_amd.navier_stokes import navier_stokes as ns
 
 
+DENSE_COARSE_MAX = 4096     # elements up to which E_0^+ is kept as a matrix
+
+
 def _centre_cofactors(xe, P, d):
   """(E, d) squared row norms k_a^2 = sum_c (det J dxi_a / dx_c)^2 of the
   Jacobian of the element's multilinear map at its centre."""
@@ -146,6 +149,9 @@ class SchwarzPressurePreconditioner:
                               else max(8, int(np.ceil(
                                   np.sqrt(lmax / lmin) * np.log(200.0) / 2))))
     self.project = ns._NullspaceProjection(sem)
+    # with the dense coarse level every step of an apply is plain device work
+    # on fixed buffers: a CG iteration that uses it can be replayed as a graph
+    self.capturable = self.E0_pinv is not None
 
   # ------------------------------------------------------------- coarse level
   def _build_coarse(self, q, dtype, dev):
@@ -218,6 +224,13 @@ class SchwarzPressurePreconditioner:
       got = np.sort(exc.eigenvalues)
       lmin = float(got[-1]) if len(got) >= k else lmax / (4.0 * E ** (2.0 / d))
     self.coarse_bounds = (0.8 * max(lmin, 1e-12 * lmax), 1.05 * lmax)
+    # small coarse problems (a few thousand elements: launch-bound steps): the
+    # pseudo-inverse as a dense matrix, one matrix-vector product per apply
+    self.E0_pinv = None
+    if E <= DENSE_COARSE_MAX:
+      self.E0_pinv = torch.as_tensor(
+          np.linalg.pinv(E0.toarray(), rcond=1e-10, hermitian=True),
+          dtype=dtype, device=dev)
 
   def coarse_matvec(self, x):
     return (self.E0_vals * x[self.E0_cols]).sum(dim=1)
@@ -227,6 +240,8 @@ class SchwarzPressurePreconditioner:
     polynomial of the Jacobi-scaled coarse matrix (`sfem_ell_chebyshev`: one
     small launch per step, no inner products, exactly linear and symmetric);
     `coarse_solver = 'cg'` keeps the truncated CG of the first version."""
+    if self.E0_pinv is not None and self.coarse_solver == 'chebyshev':
+      return torch.mv(self.E0_pinv, b)
     if self.coarse_solver == 'cg':
       return self._coarse_solve_cg(b)
     from swirl_fem_amd import _ops
