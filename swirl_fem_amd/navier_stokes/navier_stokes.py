@@ -795,8 +795,12 @@ class StokesSEM:
                       graph=small(rhs) and (default_projection or getattr(
                           pressure_preconditioner, 'capturable', False)),
                       reduce_fn=self._reduce_fn(),
-                      **(keep('E', float(dt), int(time_order))
-                         if default_projection and small(rhs) else {}))
+                      **(keep('E', float(dt), int(time_order),
+                              None if default_projection
+                              else id(pressure_preconditioner))
+                         if small(rhs) and (default_projection or getattr(
+                             pressure_preconditioner, 'capturable', False))
+                         else {}))
     if hist is not None:
       hist.update(dp, dp0, E_)
     aux['dp_info'] = info
