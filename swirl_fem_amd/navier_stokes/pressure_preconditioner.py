@@ -205,6 +205,18 @@ class SchwarzPressurePreconditioner:
     resid = np.abs(E0 @ np.ones(E)).max() / max(np.abs(E0.diagonal()).max(),
                                                 1e-300)
     self.coarse_singular = bool(resid < 1e-8)
+    # small coarse problems (a few thousand elements: launch-bound steps): the
+    # pseudo-inverse as a dense matrix, one matrix-vector product per apply
+    self.E0_pinv = None
+    if E <= DENSE_COARSE_MAX:
+      dense = torch.as_tensor(E0.toarray(), dtype=torch.float64, device=dev)
+      w, V = torch.linalg.eigh(dense)
+      keep = w > 1e-10 * w.abs().max()
+      winv = torch.where(keep, 1.0 / torch.where(keep, w, torch.ones_like(w)),
+                         torch.zeros_like(w))
+      self.E0_pinv = ((V * winv[None, :]) @ V.t()).to(dtype).contiguous()
+      self.coarse_bounds = (1.0, 2.0)          # (not used)
+      return
     # spectrum of D^-1 E_0 on the complement of the constants: Lanczos (host,
     # SciPy, setup only) for the two ends; the Chebyshev polynomial is built
     # for [lmin, lmax] and stays positive definite as long as lmax is a bound
@@ -224,13 +236,6 @@ class SchwarzPressurePreconditioner:
       got = np.sort(exc.eigenvalues)
       lmin = float(got[-1]) if len(got) >= k else lmax / (4.0 * E ** (2.0 / d))
     self.coarse_bounds = (0.8 * max(lmin, 1e-12 * lmax), 1.05 * lmax)
-    # small coarse problems (a few thousand elements: launch-bound steps): the
-    # pseudo-inverse as a dense matrix, one matrix-vector product per apply
-    self.E0_pinv = None
-    if E <= DENSE_COARSE_MAX:
-      self.E0_pinv = torch.as_tensor(
-          np.linalg.pinv(E0.toarray(), rcond=1e-10, hermitian=True),
-          dtype=dtype, device=dev)
 
   def coarse_matvec(self, x):
     return (self.E0_vals * x[self.E0_cols]).sum(dim=1)
