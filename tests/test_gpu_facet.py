@@ -596,9 +596,9 @@ def test_cg_with_layered_assembly(dtype, monkeypatch):
   `SFEM_DETERMINISTIC=0` (atomically accumulated sums) agrees to rounding."""
   from swirl_fem_amd.linalg.cg import CGRunner, cg
   P = 8
-  monkeypatch.setenv('SFEM_CHAIN_LEN', '3')
+  monkeypatch.setenv('SFEM_CHAIN_LEN', '2')
   rng = F32Rng(11)
-  rp = f32_mesh(make_mesh(3, P, 'stretched', rng), dtype)
+  rp = f32_mesh(make_mesh(2, P, 'stretched', rng), dtype)
   mesh = rp.finalize(device=DEV, dtype=dtype)
   fes = FiniteElementSpace.create(
       mesh, Quadrature1D.create_from_nodes_1d(Nodes1D.create(P, GLL)))
