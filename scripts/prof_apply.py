@@ -15,7 +15,13 @@ fes = FiniteElementSpace.create(mesh, Quadrature1D.create_from_nodes_1d(grid))
 op = fes.helmholtz_operator(mesh.physical_masks.get('boundary'))
 u = torch.randn(mesh.num_nodes, dtype=torch.float64, device=dev)
 out = torch.empty_like(u)
-for _ in range(reps):
-  op.apply(u, 0.0, 1.0, out=out)
+if os.environ.get('LAYERED', '0') == '1':     # the apply CG issues (round 4)
+  ext = op.new_extended()
+  for _ in range(reps):
+    op.apply_layered(u, ext, 0.0, 1.0)
+  out = ext
+else:
+  for _ in range(reps):
+    op.apply(u, 0.0, 1.0, out=out)
 torch.cuda.synchronize()
 print('done', float(out.abs().max()))
