@@ -562,8 +562,7 @@ def rank_main(args, world, rank, device):
                                             ngeo=ngeo)
   kernel_bytes = op.bytes_per_apply(args.mass_coeff,
                                     layered=layered is not None)
-  layer_reads = (0 if layered is None
-                 else sizeof * sum(ln for ln, _ in layered.layers))
+  layer_reads = 0 if layered is None else sizeof * layered.read
   achieved = kernel_bytes / (kern_ms * 1e-3) / 1e9
   traffic, traffic_sha = measured_traffic(args.n, args.p, args.dtype,
                                           args.geometry, args.jitter)

@@ -589,6 +589,8 @@ int sfem_cg_scalars_n(double* scalars, int phase, double maxiter, double tol,
 int sfem_cg_update_r_layered_det(void* r, const void* ap_ext, int64_t count,
                                  const int64_t* layer_len,
                                  const int64_t* layer_off, int num_layers,
+                                 const uint8_t* layer_masks,
+                                 const int64_t* mask_off,
                                  double* scalars, double* rr_partials,
                                  int64_t rr_capacity, int64_t* num_rr,
                                  int dtype, sfem_stream_t stream);
@@ -627,11 +629,18 @@ int sfem_cg_flush_x(void* x, const void* pring, int64_t ring_stride,
  * where it streams Ap anyway; sfem_fold_layers writes the assembled values
  * back into ext[0 .. count) for every other consumer.                         */
 #define SFEM_MAX_LAYERS 15
+/* layer_masks / mask_off (optional, NULL = read every layer in full): one byte
+ * per SFEM_LAYER_CHUNK nodes of a layer, layer k's bytes starting at
+ * layer_masks[mask_off[k]] (device array, host offsets; mask_off[k] < 0 = no
+ * mask for that layer); 0 = no element writes into the chunk (it holds zeros
+ * and is not read).                                                          */
+#define SFEM_LAYER_CHUNK 512
 int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
                              const int64_t* layer_len,
                              const int64_t* layer_off, int num_layers,
-                             double* scalars, int fuse_rr, int dtype,
-                             sfem_stream_t stream);
+                             const uint8_t* layer_masks,
+                             const int64_t* mask_off, double* scalars,
+                             int fuse_rr, int dtype, sfem_stream_t stream);
 int sfem_fold_layers(void* out_ext, int64_t count, const int64_t* layer_len,
                      const int64_t* layer_off, int num_layers, int dtype,
                      sfem_stream_t stream);

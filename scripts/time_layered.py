@@ -53,7 +53,11 @@ if plan is not None:
   r = torch.randn(N, dtype=dt, device=dev)
   res['update_r_ms'] = timed(lambda: _ops.cg_update_r(r, out, scal, 2))
   res['update_r_layered_ms'] = timed(
+      lambda: _ops.cg_update_r_layered(r, ext, plan.layers, scal, 2,
+                                       masks=plan.masks))
+  res['update_r_layered_unmasked_ms'] = timed(
       lambda: _ops.cg_update_r_layered(r, ext, plan.layers, scal, 2))
+  res['layer_values_read'] = plan.read
   res['fold_ms'] = timed(lambda: _ops.fold_layers(ext, N, plan.layers))
 b = torch.randn(N, dtype=dt, device=dev) * ~mesh.physical_masks['boundary']
 for name, env in (('cg_layered_ms', '1'), ('cg_atomic_ms', '0')):

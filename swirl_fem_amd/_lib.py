@@ -26,6 +26,7 @@ SFEM_DOT_SLOTS = 1024
 SFEM_CG_MEAN_SUMS = 256    # 2 parities x (64 sums of 1.r + 64 sums of w.r)
 SFEM_MAX_LAYERS = 15
 SFEM_FOLD_GROUPS = 256
+SFEM_LAYER_CHUNK = 512
 SFEM_CG_LAZY_MAX = 8
 
 c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,
@@ -123,7 +124,7 @@ SIGNATURES = {
     'sfem_cg_update_r': [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_cg_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
     'sfem_cg_update_r_layered': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
-                                 c_ptr, c_i32, c_i32, c_ptr],
+                                 c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_kernarg_selftest': [c_ptr, c_ptr],
     'sfem_fdm_solve': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                        c_i32, c_i32, c_ptr],
@@ -133,7 +134,8 @@ SIGNATURES = {
     'sfem_cg_scalars_n': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr, c_i64,
                           c_ptr],
     'sfem_cg_update_r_layered_det': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,
-                                     c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr],
+                                     c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
+                                     c_i32, c_ptr],
     'sfem_cg_update_xp_lazy': [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr,
                                c_i32, c_i32, c_ptr],
     'sfem_cg_flush_x': [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32,

@@ -640,25 +640,41 @@ def _layer_arrays(layers):
           arr(*[int(l[1]) for l in layers]) if n else arr(0), n)
 
 
-def cg_update_r_layered(r, ap_ext, layers, scalars, fuse_rr):
-  """r -= alpha (Ap assembled from its layers) (+ gamma_new += r.r)."""
+def _mask_args(masks, n):
+  """(device pointer, host offsets) of a `(bytes, offsets)` layer-mask pair."""
+  if masks is None:
+    return None, None
+  data, offs = masks
+  arr = ctypes.c_int64 * max(n, 1)
+  return _ptr(data), arr(*[int(o) for o in offs])
+
+
+def cg_update_r_layered(r, ap_ext, layers, scalars, fuse_rr, masks=None):
+  """r -= alpha (Ap assembled from its layers) (+ gamma_new += r.r).
+  `masks = (uint8 device tensor, per-layer offsets)`: chunks of
+  SFEM_LAYER_CHUNK nodes that no element writes are not read."""
   dev = _dev(r, ap_ext, scalars)
   ln, off, n = _layer_arrays(layers)
+  mptr, moff = _mask_args(masks, n)
   with torch.cuda.device(dev):
     _lib.check(_lib.load().sfem_cg_update_r_layered(
-        _ptr(r), _ptr(ap_ext), r.numel(), ln, off, n, _ptr(scalars),
-        int(fuse_rr), _dtype_code(r), _stream(dev)), 'sfem_cg_update_r_layered')
+        _ptr(r), _ptr(ap_ext), r.numel(), ln, off, n, mptr, moff,
+        _ptr(scalars), int(fuse_rr), _dtype_code(r), _stream(dev)),
+        'sfem_cg_update_r_layered')
 
 
-def cg_update_r_layered_det(r, ap_ext, layers, scalars, rr_partials):
+def cg_update_r_layered_det(r, ap_ext, layers, scalars, rr_partials,
+                            masks=None):
   """The same with r.r left as STORED per-workgroup sums in `rr_partials`
   (summed in index order by `cg_scalars_n(..., 8, ...)`): returns how many."""
   dev = _dev(r, ap_ext, scalars, rr_partials)
   ln, off, n = _layer_arrays(layers)
+  mptr, moff = _mask_args(masks, n)
   count = ctypes.c_int64(0)
   with torch.cuda.device(dev):
     _lib.check(_lib.load().sfem_cg_update_r_layered_det(
-        _ptr(r), _ptr(ap_ext), r.numel(), ln, off, n, _ptr(scalars),
+        _ptr(r), _ptr(ap_ext), r.numel(), ln, off, n, mptr, moff,
+        _ptr(scalars),
         _ptr(rr_partials), rr_partials.numel(), ctypes.byref(count),
         _dtype_code(r), _stream(dev)), 'sfem_cg_update_r_layered_det')
   return count.value

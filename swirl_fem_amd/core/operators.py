@@ -249,6 +249,11 @@ class LayerPlan:
   parts: list
   written: int
   num_nodes: int
+  # (uint8 device tensor, per-layer offsets): byte c of a layer = 1 iff some
+  # element writes into its nodes [512 c, 512 (c + 1)); the consumers skip the
+  # other chunks (zeros).  `read` = layer values they then read per pass.
+  masks: tuple | None = None
+  read: int = 0
 
 
 def build_layer_plan(facet_parts, num_elements, num_nodes, P):
@@ -343,8 +348,24 @@ def build_layer_plan(facet_parts, num_elements, num_nodes, P):
   written = int((writer.to(torch.int64) * count[None]).sum())
   parts = [dict(q, layered_table=tab2, layered_chains=use_chains and
                 'chains' in q) for q in facet_parts]
+  # which chunks of each layer are written at all (only shared facets reach a
+  # layer beyond the nodal vector: at most (P - 2)^2 <= 100 nodes, so a block
+  # touches the chunks of its two ends and no other)
+  chunk = _lib.SFEM_LAYER_CHUNK
+  flat_layer, flat_w = layer, writer.reshape(-1)
+  lo_f, hi_f = lo.reshape(-1), hi.reshape(-1)
+  bytes_, moffs, read = [], [], 0
+  for k, ln in enumerate(lens, start=1):
+    m = torch.zeros((ln + chunk - 1) // chunk, dtype=torch.uint8, device=dev)
+    sel = flat_w & (flat_layer == k)
+    m[lo_f[sel] // chunk] = 1
+    m[(hi_f[sel] - 1) // chunk] = 1
+    moffs.append(sum(b.numel() for b in bytes_))
+    bytes_.append(m)
+    read += min(int(m.sum()) * chunk, ln)
+  masks = (torch.cat(bytes_), moffs) if bytes_ else None
   return LayerPlan(layers=list(zip(lens, offs)), extent=extent, parts=parts,
-                   written=written, num_nodes=N)
+                   written=written, num_nodes=N, masks=masks, read=read)
 
 
 def _cluster_limits(fespace):

@@ -838,6 +838,11 @@ struct LayerDesc {
   int nl;
   int64_t len[SFEM_MAX_LAYERS];   // multiples of the 16-byte vector width
   int64_t off[SFEM_MAX_LAYERS];
+  // optional: one byte per SFEM_LAYER_CHUNK nodes of the layer, 0 = no element
+  // writes into that chunk (it holds zeros: not read).  The refiner numbers
+  // runs of edge blocks between runs of face blocks, so most of the second and
+  // third layer of a hexahedral mesh is such chunks.
+  const uint8_t* mask[SFEM_MAX_LAYERS];
 };
 
 template <typename T, bool NT>
@@ -848,6 +853,7 @@ __device__ __forceinline__ typename Vec16<T>::type add_layers(
   constexpr int VN = Vec16<T>::N;
   for (int k = 0; k < ld.nl; ++k) {
     if (i * VN >= ld.len[k]) break;            // lengths do not increase
+    if (ld.mask[k] && !ld.mask[k][(i * VN) / SFEM_LAYER_CHUNK]) continue;
     const V l = ld16<T, NT>(reinterpret_cast<const V*>(ap + ld.off[k]) + i);
 #pragma unroll
     for (int c = 0; c < VN; ++c)
@@ -930,7 +936,9 @@ fold_layers_kernel(T* __restrict__ out, int64_t count, LayerDesc ld) {
 
 static int make_layer_desc(const char* who, const int64_t* layer_len,
                            const int64_t* layer_off, int num_layers,
-                           int64_t count, int vn, LayerDesc* ld) {
+                           int64_t count, int vn, LayerDesc* ld,
+                           const uint8_t* masks = nullptr,
+                           const int64_t* mask_off = nullptr) {
   SFEM_REQUIRE(num_layers >= 0 && num_layers <= SFEM_MAX_LAYERS,
                "%s: %d layers (at most %d)", who, num_layers, SFEM_MAX_LAYERS);
   SFEM_REQUIRE(num_layers == 0 || (layer_len && layer_off),
@@ -946,7 +954,10 @@ static int make_layer_desc(const char* who, const int64_t* layer_len,
                  (long long)layer_off[k], (long long)count);
     ld->len[k] = layer_len[k];
     ld->off[k] = layer_off[k];
+    ld->mask[k] = masks && mask_off && mask_off[k] >= 0 ? masks + mask_off[k]
+                                                        : nullptr;
   }
+  for (int k = num_layers; k < SFEM_MAX_LAYERS; ++k) ld->mask[k] = nullptr;
   return SFEM_OK;
 }
 
@@ -1548,8 +1559,9 @@ int sfem_cg_update_r(void* r, const void* ap, int64_t count, double* scalars,
 int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
                              const int64_t* layer_len,
                              const int64_t* layer_off, int num_layers,
-                             double* scalars, int fuse_rr, int dtype,
-                             sfem_stream_t stream) {
+                             const uint8_t* layer_masks,
+                             const int64_t* mask_off, double* scalars,
+                             int fuse_rr, int dtype, sfem_stream_t stream) {
   SFEM_REQUIRE(count >= 0 && scalars, "sfem_cg_update_r_layered: bad arguments");
   if (count == 0) return SFEM_OK;
   SFEM_REQUIRE(r && ap_ext, "sfem_cg_update_r_layered: null pointer");
@@ -1560,7 +1572,8 @@ int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
   LayerDesc ld;
   const int rc = make_layer_desc("sfem_cg_update_r_layered", layer_len,
                                  layer_off, num_layers, count,
-                                 dtype == SFEM_F64 ? 2 : 4, &ld);
+                                 dtype == SFEM_F64 ? 2 : 4, &ld, layer_masks,
+                                 mask_off);
   if (rc != SFEM_OK) return rc;
   DISPATCH_DTYPE(dtype, {
     const int grid = fuse_rr == 2 ? stream_grid(count, 512 * 2)
@@ -1576,6 +1589,8 @@ int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
 int sfem_cg_update_r_layered_det(void* r, const void* ap_ext, int64_t count,
                                  const int64_t* layer_len,
                                  const int64_t* layer_off, int num_layers,
+                                 const uint8_t* layer_masks,
+                                 const int64_t* mask_off,
                                  double* scalars, double* rr_partials,
                                  int64_t rr_capacity, int64_t* num_rr,
                                  int dtype, sfem_stream_t stream) {
@@ -1590,7 +1605,8 @@ int sfem_cg_update_r_layered_det(void* r, const void* ap_ext, int64_t count,
   LayerDesc ld;
   const int rc = make_layer_desc("sfem_cg_update_r_layered_det", layer_len,
                                  layer_off, num_layers, count,
-                                 dtype == SFEM_F64 ? 2 : 4, &ld);
+                                 dtype == SFEM_F64 ? 2 : 4, &ld, layer_masks,
+                                 mask_off);
   if (rc != SFEM_OK) return rc;
   DISPATCH_DTYPE(dtype, {
     int grid = stream_grid(count, 512 * 2);

@@ -365,12 +365,12 @@ class CGRunner:
     if self.layered is not None and self.det is not None and self.fuse_rr:
       n = _ops.cg_update_r_layered_det(
           self.r, Ap, self.layered.layers, s.t,
-          self.det[1][:RR_PARTIALS])
+          self.det[1][:RR_PARTIALS], masks=self.layered.masks)
       _ops.cg_scalars_n(s.t, 8, self.maxiter, self.tol, self.atol,
                         self.det[1], n)
     elif self.layered is not None:
       _ops.cg_update_r_layered(self.r, Ap, self.layered.layers, s.t,
-                               self.fuse_rr)
+                               self.fuse_rr, masks=self.layered.masks)
     else:
       for rr, aa in zip(_leaves(self.r), _leaves(Ap)):
         _ops.cg_update_r(layout.flat(rr), layout.flat(layout.like(aa, rr)),

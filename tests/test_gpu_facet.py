@@ -565,6 +565,20 @@ def test_layered_assembly_matches_oracle(P, chain, dtype, monkeypatch):
           want = float((u * ref).sum())
           scale = float(np.abs(u * ref).sum())
           assert abs(float(parts.sum()) - want) <= 10 * tol * scale
+          # r -= alpha (Ap from its layers): skipping the chunks nobody writes
+          # (`plan.masks`) changes nothing, bit for bit
+          scal = torch.zeros(_lib.SFEM_CG_NSCALARS, dtype=torch.float64,
+                             device=DEV)
+          scal[0], scal[1] = 1.0, 3.0
+          r_m, r_u = ud.clone(), ud.clone()
+          _ops.cg_update_r_layered(r_m, raw, plan.layers, scal, 0,
+                                   masks=plan.masks)
+          _ops.cg_update_r_layered(r_u, raw, plan.layers, scal, 0)
+          assert torch.equal(r_m, r_u)
+          want_r = ud.double() - (1.0 / 3.0) * got.double()
+          assert float((r_m.double() - want_r).abs().max()) <= 4 * tol * float(
+              want_r.abs().max())
+          assert 0 < plan.read <= sum(l for l, _ in plan.layers)
           # the same buffer again (slots nobody writes still zero), and a
           # fresh one: bit for bit the same
           op.apply_layered(ud, ext, l0, l1)
