@@ -644,6 +644,14 @@ int sfem_cg_update_r_layered(void* r, const void* ap_ext, int64_t count,
 int sfem_fold_layers(void* out_ext, int64_t count, const int64_t* layer_len,
                      const int64_t* layer_off, int num_layers, int dtype,
                      sfem_stream_t stream);
+/* The same at `num_idx` DISTINCT nodes idx[] (negative entries skipped), and
+ * the folded layer slots are cleared: a partitioned operator makes its
+ * interface values whole before it packs them for the neighbours
+ * (core/gather_scatter.py:247-248), later consumers of the layers find zeros. */
+int sfem_fold_layers_at(void* out_ext, const int64_t* idx, int64_t num_idx,
+                        int64_t count, const int64_t* layer_len,
+                        const int64_t* layer_off, int num_layers, int dtype,
+                        sfem_stream_t stream);
 int sfem_cg_update_r_mean(void* r, const void* ap, const void* w,
                           int64_t count, double* scalars, double* sums,
                           int dtype, sfem_stream_t stream);

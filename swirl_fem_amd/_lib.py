@@ -131,6 +131,8 @@ SIGNATURES = {
     'sfem_ell_chebyshev': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                            c_i32, c_i32, c_dbl, c_dbl, c_i32, c_ptr],
     'sfem_fold_layers': [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
+    'sfem_fold_layers_at': [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32,
+                            c_i32, c_ptr],
     'sfem_cg_scalars_n': [c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr, c_i64,
                           c_ptr],
     'sfem_cg_update_r_layered_det': [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i32,

@@ -689,6 +689,20 @@ def cg_scalars_n(scalars, phase, maxiter, tol, atol, partials, num_partials):
         _ptr(partials), int(num_partials), _stream(dev)), 'sfem_cg_scalars_n')
 
 
+def fold_layers_at(ext, idx, count, layers):
+  """ext[idx] += its layers there, the folded slots cleared (in place); `idx`:
+  distinct node positions (int64 device tensor)."""
+  dev = _dev(ext, idx)
+  if idx.dtype != torch.int64:
+    raise ValueError('fold_layers_at: int64 node positions')
+  ln, off, n = _layer_arrays(layers)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_fold_layers_at(
+        _ptr(ext), _ptr(idx), idx.numel(), int(count), ln, off, n,
+        _dtype_code(ext), _stream(dev)), 'sfem_fold_layers_at')
+  return ext
+
+
 def fdm_solve(r, pel, S, cases, inv_ev, ndim, Pp):
   """z_e = (S (x) ..) [inv_ev_e .* (S (x) ..)^T r_e] for every element
   (`sfem_fdm_solve`); `pel` (E, Pp^d) int64 or None for element-contiguous

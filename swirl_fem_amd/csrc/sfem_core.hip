@@ -934,6 +934,30 @@ fold_layers_kernel(T* __restrict__ out, int64_t count, LayerDesc ld) {
   }
 }
 
+// The same at a list of distinct nodes, and the folded layer slots are cleared:
+// a partitioned operator makes the values of its interface nodes whole before
+// it packs them for the neighbours, and whoever adds the layers up afterwards
+// (`r -= alpha Ap`) finds zeros there.
+template <typename T>
+__global__ void __launch_bounds__(256)
+fold_layers_at_kernel(T* __restrict__ ext, const int64_t* __restrict__ idx,
+                      int64_t count, LayerDesc ld) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count;
+       t += stride) {
+    const int64_t n = idx[t];
+    if (n < 0) continue;
+    T a = ext[n];
+    for (int k = 0; k < ld.nl; ++k) {
+      if (n >= ld.len[k]) break;
+      T* slot = ext + ld.off[k] + n;
+      a += *slot;
+      *slot = T(0);
+    }
+    ext[n] = a;
+  }
+}
+
 static int make_layer_desc(const char* who, const int64_t* layer_len,
                            const int64_t* layer_off, int num_layers,
                            int64_t count, int vn, LayerDesc* ld,
@@ -1615,6 +1639,29 @@ int sfem_cg_update_r_layered_det(void* r, const void* ap_ext, int64_t count,
     launch_update_r_layered<T>(1, streams_past_caches(count, sizeof(T)), grid,
                                as_stream(stream), (T*)r, (const T*)ap_ext,
                                count, ld, scalars, rr_partials);
+  });
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+int sfem_fold_layers_at(void* out_ext, const int64_t* idx, int64_t num_idx,
+                        int64_t count, const int64_t* layer_len,
+                        const int64_t* layer_off, int num_layers, int dtype,
+                        sfem_stream_t stream) {
+  SFEM_REQUIRE(count >= 0 && num_idx >= 0, "sfem_fold_layers_at: bad sizes");
+  if (num_idx == 0 || num_layers == 0) return SFEM_OK;
+  SFEM_REQUIRE(out_ext && idx, "sfem_fold_layers_at: null pointer");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_fold_layers_at: unknown dtype %d", dtype);
+  LayerDesc ld;
+  const int rc = make_layer_desc("sfem_fold_layers_at", layer_len, layer_off,
+                                 num_layers, count, dtype == SFEM_F64 ? 2 : 4,
+                                 &ld);
+  if (rc != SFEM_OK) return rc;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((fold_layers_at_kernel<T>),
+                       dim3(stream_grid(num_idx, 256)), dim3(256), 0,
+                       as_stream(stream), (T*)out_ext, idx, num_idx, ld);
   });
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;

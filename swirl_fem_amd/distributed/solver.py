@@ -24,6 +24,17 @@ from swirl_fem_amd.distributed import comm
 from swirl_fem_amd.linalg import cg as cg_lib
 
 
+def _exchange_layered_(ext, num_nodes, layer_plan, plan, group):
+  """QQ^T on an extended (layered) operator result: the interface nodes are
+  made whole first (`sfem_fold_layers_at`: their layers added up and cleared),
+  then exchanged in place like any nodal vector."""
+  from swirl_fem_amd import _ops
+  _ops.fold_layers_at(ext, plan.interface_nodes(ext.device), num_nodes,
+                      layer_plan.layers)
+  comm.neighbor_exchange_(ext[:num_nodes], plan, group)
+  return ext
+
+
 class PartitionedOperator:
   """Assembled action `u -> QQ^T A_local(u)` of a rank-local operator."""
 
@@ -31,6 +42,16 @@ class PartitionedOperator:
     self.local_op, self.plan, self.group = local_op, plan, group
     if hasattr(local_op, 'apply_with_dot'):
       self.apply_with_dot = self._apply_with_dot
+    if hasattr(local_op, 'apply_layered_with_dot'):
+      self.apply_layered_with_dot = self._apply_layered_with_dot
+      self.layer_plan = local_op.layer_plan
+
+  def _apply_layered_with_dot(self, u, partials, per_wave=False):
+    # the rank-local result in layers (no atomics, nothing cleared); only the
+    # interface nodes are assembled here, the rest inside `r -= alpha Ap`
+    ext = self.local_op.apply_layered_with_dot(u, partials, per_wave)
+    return _exchange_layered_(ext, u.shape[0], self.local_op.layer_plan(),
+                              self.plan, self.group)
 
   def __call__(self, u):
     return comm.neighbor_exchange_(self.local_op(u), self.plan, self.group)
@@ -65,6 +86,53 @@ class OverlappedHelmholtz:
     self.plan, self.group = plan, group
     self.lambda0, self.lambda1 = lambda0, lambda1
     self.num_boundary_elements = int(boundary.sum())
+    self.num_nodes = mesh.num_nodes
+    # layered assembly over BOTH halves (one plan: every writer of a facet,
+    # whichever half launches it, has its own layer); None = atomics
+    self._layers = self._ext = None
+    from swirl_fem_amd.core import operators
+    from swirl_fem_amd import switches
+    bp, ip = self.boundary_op.facet_parts, self.interior_op.facet_parts
+    if (bp is not None and ip is not None and
+        switches.get('SFEM_LAYERED') != '0'):
+      joint = operators.build_layer_plan(
+          list(bp) + list(ip), mesh.num_elements, mesh.num_nodes,
+          mesh.gridpoints_1d.num_points)
+      if joint is not None and not any(
+          q['geo_mode'] == operators._GEO_POINT for q in joint.parts):
+        self._layers = joint
+        self._halves = (joint.parts[:len(bp)], joint.parts[len(bp):])
+
+  def layer_plan(self):
+    return self._layers
+
+  def apply_layered_with_dot(self, u, partials, per_wave=False):
+    """The same in layered form (an extended vector owned by this object):
+    boundary elements -> interface nodes made whole -> pack + post send/recv
+    -> interior elements -> wait + unpack-add.  No atomics besides the
+    neighbours' contributions, nothing cleared."""
+    from swirl_fem_amd import _ops
+    if per_wave:
+      raise NotImplementedError('per-wave partial sums with two launches')
+    op = self.boundary_op
+    mesh = op.fespace.mesh
+    if self._ext is None:
+      self._ext = torch.zeros(self._layers.extent, dtype=op.fespace.dtype,
+                              device=op.enc.device)
+    ext, N = self._ext, self.num_nodes
+    P = mesh.gridpoints_1d.num_points
+    uu = u.to(op.fespace.dtype).contiguous()
+    _ops.helmholtz_apply_layered(uu, ext, op.enc, self._halves[0], op.host,
+                                 mesh.ndim, P, self.lambda0, self.lambda1,
+                                 partials)
+    _ops.fold_layers_at(ext, self.plan.interface_nodes(ext.device), N,
+                        self._layers.layers)
+    handle = comm.neighbor_exchange_start(ext[:N], self.plan, self.group)
+    _ops.helmholtz_apply_layered(uu, ext, op.enc, self._halves[1], op.host,
+                                 mesh.ndim, P, self.lambda0, self.lambda1,
+                                 partials)
+    comm.neighbor_exchange_finish(handle, ext[:N])
+    return ext
 
   def _apply(self, u, partials):
     l0, l1 = self.lambda0, self.lambda1

@@ -182,9 +182,10 @@ class CGRunner:
     # in layers of an extended Ap (plain stores: no atomics, no cleared range)
     # and `r -= alpha Ap` adds them up where it streams Ap anyway, in a fixed
     # order -- same sums, bitwise reproducible.  One partition, scalar field.
+    # On partitions (`reduce_fn`, `interface`) the operator hands back the
+    # layered result with its interface nodes already whole and exchanged.
     self.layered = None
-    if (self.fused_dot and self.mean is None and reduce_fn is None and
-        interface is None and self._p.dim() == 1 and
+    if (self.fused_dot and self.mean is None and self._p.dim() == 1 and
         hasattr(A, 'apply_layered_with_dot')):
       self.layered = A.layer_plan()
     # ... and with the two inner products of the iteration summed from STORED
@@ -192,7 +193,8 @@ class CGRunner:
     # workgroup of the r update) the whole iteration is bitwise reproducible
     # from run to run; costs one more scalar launch per iteration
     self.det = None
-    if self.layered is not None and switches.get('SFEM_DETERMINISTIC') != '0':
+    if (self.layered is not None and reduce_fn is None and interface is None
+        and switches.get('SFEM_DETERMINISTIC') != '0'):
       # (+ SFEM_FOLD_GROUPS: scratch of the two-stage sums behind the slots)
       pad = _lib.SFEM_FOLD_GROUPS
       self.det = (torch.zeros(A.layered_dot_slots() + pad, dtype=torch.float64,
