@@ -428,6 +428,10 @@ def test_bench_eight_ranks_with_real_kernels_on_one_gpu(flags, blocks):
   assert min(cfg['per_rank']['interface_values']) > 0
   assert cfg['verify']['status'] == 'converged', cfg['verify']
   assert cfg['verify']['rel_err_vs_manufactured'] < 1e-8, cfg['verify']
+  # the ranks' solver ran the layered assembly over its boundary / interior
+  # halves (interface nodes folded before the exchange) and the lazy x update
+  assert cfg['assembly'].startswith('layered'), cfg['assembly']
+  assert cfg['solver']['lazy_x'] is not None
   if '--periodic' in flags:
     assert cfg['periodic_dims'] == [0, 1, 2]
     assert cfg['dofs_global'] == (2 * 16 * 7) ** 3
