@@ -579,6 +579,23 @@ def test_layered_assembly_matches_oracle(P, chain, dtype, monkeypatch):
           assert float((r_m.double() - want_r).abs().max()) <= 4 * tol * float(
               want_r.abs().max())
           assert 0 < plan.read <= sum(l for l, _ in plan.layers)
+          # folding at SOME nodes first (what a partitioned operator does at
+          # its interface) moves their layer values into the nodal vector and
+          # clears the slots: the complete fold is unchanged
+          pick = torch.unique(torch.randint(
+              0, plan.layers[0][0], (200,), device=DEV,
+              generator=torch.Generator(device=DEV).manual_seed(1)))
+          pick = pick[pick < N]
+          part = raw.clone()
+          _ops.fold_layers_at(part, pick, N, plan.layers)
+          for ln, off in plan.layers:
+            inside = pick[pick < ln]
+            assert float(part[off + inside].abs().max()) == 0.0
+          assert float((part[pick] - got[pick]).abs().max()) <= 1e-14 * float(
+              got.abs().max()) * (1 if dtype == torch.float64 else 1e8)
+          assert float((_ops.fold_layers(part, N, plan.layers) - got).abs()
+                       .max()) <= (1e-14 if dtype == torch.float64 else
+                                   1e-6) * float(got.abs().max())
           # the same buffer again (slots nobody writes still zero), and a
           # fresh one: bit for bit the same
           op.apply_layered(ud, ext, l0, l1)
