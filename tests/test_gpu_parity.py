@@ -1155,6 +1155,26 @@ def test_cg_runner_reuse_keeps_the_recorded_iteration():
     for k in range(cgmod.MAX_KEPT_RUNNERS + 3):
       cg(A, bs[0], tol=1e-3, graph=True, workspace=ws, key=('dt', k))
     assert len(ws) == cgmod.MAX_KEPT_RUNNERS and 'A' not in ws
+    # least recently USED goes first: a hit moves its key to the end
+    keys = list(ws)
+    cg(A, bs[0], tol=1e-3, graph=True, workspace=ws, key=keys[0])
+    assert list(ws)[-1] == keys[0] and len(ws) == cgmod.MAX_KEPT_RUNNERS
+    cg(A, bs[0], tol=1e-3, graph=True, workspace=ws, key=('dt', 'new'))
+    assert keys[0] in ws and keys[1] not in ws
+    # a kept runner takes a right-hand side of another memory layout: a
+    # component-major (N, 3) field after a row-major one (same shape)
+    from swirl_fem_amd.core import layout
+    A3 = op.linear_operator(0.3, 1.0)
+    b_rows = (interior[:, None] * dev(rng.standard_normal((mesh.num_nodes, 3))
+                                      )).contiguous()
+    b_cm = layout.component_major(b_rows.clone())
+    assert b_rows.stride() != b_cm.stride() and b_rows.shape == b_cm.shape
+    ws3 = {}
+    x_rows, _ = cg(A3, b_rows, tol=1e-9, graph=True, workspace=ws3, key='v')
+    kept = ws3['v']
+    x_cm, _ = cg(A3, 2.0 * b_cm, tol=1e-9, graph=True, workspace=ws3, key='v')
+    assert ws3['v'] is kept                 # restarted, not rebuilt
+    assert relerr(x_cm, 2.0 * x_rows.cpu().numpy()) < 1e-8
   finally:
     cgmod.CGRunner.capture = orig
 
