@@ -1170,11 +1170,20 @@ def test_cg_runner_reuse_keeps_the_recorded_iteration():
     b_cm = layout.component_major(b_rows.clone())
     assert b_rows.stride() != b_cm.stride() and b_rows.shape == b_cm.shape
     ws3 = {}
-    x_rows, _ = cg(A3, b_rows, tol=1e-9, graph=True, workspace=ws3, key='v')
+    x_cm, _ = cg(A3, b_cm, tol=1e-9, graph=True, workspace=ws3, key='v')
     kept = ws3['v']
-    x_cm, _ = cg(A3, 2.0 * b_cm, tol=1e-9, graph=True, workspace=ws3, key='v')
+    # a dense row-major b is repacked into the kept (component-major) state ...
+    x_rows, _ = cg(A3, 2.0 * b_rows, tol=1e-9, graph=True, workspace=ws3,
+                   key='v')
     assert ws3['v'] is kept                 # restarted, not rebuilt
-    assert relerr(x_cm, 2.0 * x_rows.cpu().numpy()) < 1e-8
+    assert relerr(x_rows, 2.0 * x_cm.cpu().numpy()) < 1e-8
+    # ... a strided b of another layout gets a state of its own
+    ws4 = {}
+    cg(A3, b_rows, tol=1e-9, graph=True, workspace=ws4, key='v')
+    kept = ws4['v']
+    x2, _ = cg(A3, b_cm, tol=1e-9, graph=True, workspace=ws4, key='v')
+    assert ws4['v'] is not kept
+    assert relerr(x2, x_cm.cpu().numpy()) < 1e-8
   finally:
     cgmod.CGRunner.capture = orig
 
