@@ -684,7 +684,7 @@ def test_cg_with_layered_assembly(dtype, monkeypatch):
   M = lambda r: r / diag
   xm, im = cg(A, bd, tol=tol, M=M)
   xm_a, im_a = cg(op_a.linear_operator(0.0, 1.0), bd, tol=tol, M=M)
-  assert abs(im['num_iterations'] - im_a['num_iterations']) <= slack
+  assert abs(im['num_iterations'] - im_a['num_iterations']) <= slack + 2
   assert relerr(xm, xm_a.double().cpu().numpy()) < (1e-9 if f64 else 2e-3)
 
 
