@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFEM_ABI_VERSION 5
+#define SFEM_ABI_VERSION 6
 
 enum { SFEM_F32 = 0, SFEM_F64 = 1 };
 enum {
@@ -683,6 +683,52 @@ int sfem_ell_chebyshev(const int32_t* cols, const void* vals, const void* dinv,
                        const void* b, void* x, void* work, int64_t n,
                        int width, int steps, double lmin, double lmax,
                        int dtype, sfem_stream_t stream);
+/* --------------------------------------------- CG for an ensemble (vmap) ---
+ * B independent CG recurrences in one set of launches: what the reference
+ * gets from jax.vmap of its solver step over an ensemble (niles/train.py:232,
+ * :262-264).  Member m owns the contiguous range [m len, (m + 1) len) of every
+ * vector (B disjoint copies of the mesh seen as one mesh, so the operator
+ * kernels serve all members in one launch unchanged) and the
+ * SFEM_ENS_NSCALARS doubles at scalars + m SFEM_ENS_NSCALARS, same slots as
+ * the single solve above ([0] gamma [1] p.Ap [3] alpha [4] beta [5] b.b
+ * [6] atol2 [7] done [8] iterations [9] active in this iteration [10] status).
+ * Each member follows linalg/cg.py:60-97 with its own step lengths and stop
+ * test; a member that has stopped is a no-op from then on.  Inner products are
+ * stored partial sums, `partials`: members x 2 x SFEM_ENS_GROUPS doubles,
+ * added in index order by the consumers (no atomics, nothing to clear).
+ * One iteration:
+ *     Ap = A p;  sfem_ens_dot(p, Ap, which = 0);  sfem_ens_update_r;
+ *     z = M r;   sfem_ens_dot(r, z, which = 1);   sfem_ens_close;
+ *     sfem_ens_update_xp
+ * and before the first: sfem_ens_dot(b, b, 0), sfem_ens_dot(r, z, 1),
+ * sfem_ens_init.                                                             */
+#define SFEM_ENS_NSCALARS 16
+#define SFEM_ENS_GROUPS 32
+#define SFEM_ENS_MAX_MEMBERS 4096
+int sfem_ens_dot(const void* a, const void* b, int64_t len, int members,
+                 double* partials, int which, int dtype, sfem_stream_t stream);
+int sfem_ens_init(double* scalars, const double* partials, int members,
+                  double maxiter, double tol, double atol,
+                  sfem_stream_t stream);
+/* r -= alpha Ap, alpha = gamma / p.Ap from the partial sums                  */
+int sfem_ens_update_r(void* r, const void* ap, int64_t len, int members,
+                      const double* scalars, const double* partials,
+                      int dtype, sfem_stream_t stream);
+/* closes the iteration of every member: alpha, beta, gamma <- gamma_new,
+ * counter, stop test (cg.py:68-73 + the breakdown guards of the single solve) */
+int sfem_ens_close(double* scalars, const double* partials, int members,
+                   double maxiter, sfem_stream_t stream);
+/* x += alpha p;  p = z + beta p  for the members active in this iteration    */
+int sfem_ens_update_xp(void* x, void* p, const void* z, int64_t len,
+                       int members, const double* scalars, int dtype,
+                       sfem_stream_t stream);
+/* out_m = w_m - (b . w_m / total) 1 for every member m (b: one member's
+ * weights, len values; partials: members x SFEM_ENS_GROUPS doubles): the mean
+ * projection of the pressure solve (navier_stokes.py:73-78) per member.      */
+int sfem_ens_subtract_weighted_mean(const void* w, const void* b, double total,
+                                    void* out, double* partials, int64_t len,
+                                    int members, int dtype,
+                                    sfem_stream_t stream);
 /* y = a*x + b*y (plain fused vector update used outside the CG core)         */
 int sfem_axpby(double a, const void* x, double b, void* y, int64_t count,
                int dtype, sfem_stream_t stream);

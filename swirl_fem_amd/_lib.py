@@ -15,7 +15,7 @@ from swirl_fem_amd import switches
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SFEM_LIB: another build of the same library (kernel A/B experiments)
 LIB_PATH = switches.get('SFEM_LIB') or os.path.join(_HERE, 'libsfem_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SFEM_F32, SFEM_F64 = 0, 1
 SFEM_CG_NSCALARS_NAMED = 16
@@ -28,6 +28,9 @@ SFEM_MAX_LAYERS = 15
 SFEM_FOLD_GROUPS = 256
 SFEM_LAYER_CHUNK = 512
 SFEM_CG_LAZY_MAX = 8
+SFEM_ENS_NSCALARS = 16   # per member: the named scalars of the single solve
+SFEM_ENS_GROUPS = 32      # stored partial sums per member and inner product
+SFEM_ENS_MAX_MEMBERS = 4096
 
 c_i32, c_i64, c_dbl, c_ptr = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,
                               ctypes.c_void_p)
@@ -130,6 +133,15 @@ SIGNATURES = {
                        c_i32, c_i32, c_ptr],
     'sfem_ell_chebyshev': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                            c_i32, c_i32, c_dbl, c_dbl, c_i32, c_ptr],
+    'sfem_ens_dot': [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_i32, c_ptr],
+    'sfem_ens_init': [c_ptr, c_ptr, c_i32, c_dbl, c_dbl, c_dbl, c_ptr],
+    'sfem_ens_update_r': [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_i32,
+                          c_ptr],
+    'sfem_ens_close': [c_ptr, c_ptr, c_i32, c_dbl, c_ptr],
+    'sfem_ens_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32,
+                           c_ptr],
+    'sfem_ens_subtract_weighted_mean': [c_ptr, c_ptr, c_dbl, c_ptr, c_ptr,
+                                        c_i64, c_i32, c_i32, c_ptr],
     'sfem_fold_layers': [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr],
     'sfem_fold_layers_at': [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32,
                             c_i32, c_ptr],

@@ -733,6 +733,76 @@ def ell_chebyshev(cols, vals, dinv, b, steps, lmin, lmax, work=None):
   return x
 
 
+# ------------------------------------------------------- ensemble CG (vmap)
+def _ens_check(members, *vs):
+  dev = _dev(*vs)
+  n = vs[0].numel()
+  if n % members:
+    raise ValueError(f'{n} values do not split into {members} members')
+  for v in vs:
+    if not v.is_contiguous() or v.numel() != n or v.dtype != vs[0].dtype:
+      raise ValueError('ensemble vectors: contiguous, same size and dtype '
+                       '(member m owns [m len, (m + 1) len))')
+  return dev, n // members
+
+
+def ens_dot(a, b, members, partials, which):
+  """partials[m, which, :] = stored partial sums of a_m . b_m."""
+  dev, ln = _ens_check(members, a, b)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_dot(
+        _ptr(a), _ptr(b), ln, members, _ptr(partials), int(which),
+        _dtype_code(a), _stream(dev)), 'sfem_ens_dot')
+
+
+def ens_init(scalars, partials, members, maxiter, tol, atol):
+  dev = _dev(scalars, partials)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_init(
+        _ptr(scalars), _ptr(partials), members, float(maxiter), float(tol),
+        float(atol), _stream(dev)), 'sfem_ens_init')
+
+
+def ens_update_r(r, ap, members, scalars, partials):
+  dev, ln = _ens_check(members, r, ap)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_update_r(
+        _ptr(r), _ptr(ap), ln, members, _ptr(scalars), _ptr(partials),
+        _dtype_code(r), _stream(dev)), 'sfem_ens_update_r')
+
+
+def ens_close(scalars, partials, members, maxiter):
+  dev = _dev(scalars, partials)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_close(
+        _ptr(scalars), _ptr(partials), members, float(maxiter), _stream(dev)),
+        'sfem_ens_close')
+
+
+def ens_update_xp(x, p, z, members, scalars):
+  dev, ln = _ens_check(members, x, p, z)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_update_xp(
+        _ptr(x), _ptr(p), _ptr(z), ln, members, _ptr(scalars), _dtype_code(x),
+        _stream(dev)), 'sfem_ens_update_xp')
+
+
+def ens_subtract_weighted_mean(w, b, total, members, partials, out=None):
+  """out_m = w_m - (b . w_m / total) 1 for every member (b: one member)."""
+  w, b = w.contiguous(), b.contiguous()
+  if out is None:
+    out = torch.empty_like(w)
+  dev, ln = _ens_check(members, w, out)
+  if b.numel() != ln or b.dtype != w.dtype:
+    raise ValueError('ens_subtract_weighted_mean: weights of one member')
+  _dev(b, partials)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_subtract_weighted_mean(
+        _ptr(w), _ptr(b), float(total), _ptr(out), _ptr(partials), ln, members,
+        _dtype_code(w), _stream(dev)), 'sfem_ens_subtract_weighted_mean')
+  return out
+
+
 def fold_layers(ext, count, layers):
   """ext[:count] += its layers (in place); returns the view ext[:count]."""
   dev = _dev(ext)

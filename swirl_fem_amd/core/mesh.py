@@ -108,6 +108,37 @@ class Mesh:
     kw.setdefault('_cache', {})
     return dataclasses.replace(self, **kw)
 
+  def replicate(self, members: int) -> 'Mesh':
+    """`members` disjoint copies of this mesh as ONE mesh: copy b owns the
+    nodes [b N, (b + 1) N) and the elements [b E, (b + 1) E), periodic images
+    stay inside their copy.  An ensemble of fields on the same mesh is one
+    field on this mesh ((B, N, ...) viewed as (B N, ...)), so every operator
+    kernel works on all members in a single launch (`StokesSEM.ensemble`)."""
+    if members < 1:
+      raise ValueError(f'members must be positive; got {members}')
+    if self.axis_name is not None or self.neighbor_plan is not None:
+      raise NotImplementedError('ensembles of a partitioned mesh')
+    if members == 1:
+      return self
+    N, dev = self.num_nodes, self.device
+    off = torch.arange(members, dtype=torch.int32, device=dev) * N
+    elements = (self.elements[None] + off[:, None, None]).reshape(
+        -1, self.num_nodes_per_element)
+    node_indices = (self.node_indices[None] + off[:, None]).reshape(-1)
+    gi, ui = self.exchange_gather_indices, self.exchange_unique_indices
+    if gi is not None and gi.numel():
+      gi = (gi[None] + off[:, None]).reshape(-1)
+      if ui is not None:
+        ui = np.asarray(ui)
+        width = int(ui.max()) + 1 if ui.size else 0
+        ui = (ui[None] + width * np.arange(members)[:, None]).reshape(-1)
+    return self.replace(
+        node_coords=self.node_coords.repeat(members, 1), elements=elements,
+        node_indices=node_indices,
+        physical_masks={k: v.repeat(members)
+                        for k, v in self.physical_masks.items()},
+        exchange_gather_indices=gi, exchange_unique_indices=ui)
+
   # ------------------------------------------------------------- properties
   @property
   def ndim(self) -> int:

@@ -99,6 +99,15 @@ def bdfk_coeffs(k: int) -> np.ndarray:
 def _solve(differentiable, A, b, **kwargs):
   """`cg(A, b, **kwargs)`; with `differentiable`, autograd sees the solve as
   `x = A^-1 b` (adjoint by a second solve, `linalg.cg.symmetric_solve`)."""
+  members = kwargs.pop('members', 1)
+  if members > 1:
+    # an ensemble on the replicated mesh: one recurrence per member
+    # (linalg/cg_ensemble.py)
+    if differentiable or kwargs.pop('reduce_fn', None) is not None:
+      raise NotImplementedError('ensembles: one partition, no autograd '
+                                '(differentiate member by member)')
+    from swirl_fem_amd.linalg.cg_ensemble import cg_ensemble
+    return cg_ensemble(A, b, members, **kwargs)
   if not differentiable:
     return cg(A, b, **kwargs)
   info = {}
@@ -134,7 +143,7 @@ class _NullspaceProjection:
 
   def __init__(self, sem):
     self.sem = sem
-    if not sem.is_partitioned and _FUSED_DOTS():
+    if not sem.is_partitioned and _FUSED_DOTS() and sem.members == 1:
       self.apply_with_dot = self._apply_with_dot
 
   def __call__(self, p):
@@ -150,7 +159,7 @@ class _NullspaceProjection:
     sem = self.sem
     pmesh = sem.pressure.pspace.mesh
     gi = pmesh.exchange_gather_indices
-    if (sem.is_partitioned or pmesh.axis_name is not None or
+    if (sem.members > 1 or sem.is_partitioned or pmesh.axis_name is not None or
         pmesh.neighbor_plan is not None or
         (gi is not None and gi.numel() != 0)):
       return None
@@ -221,6 +230,8 @@ def _pressure_mass_ones(sem, dtype, device):
     ones = torch.ones(sem.pressure.pspace.mesh.num_nodes, dtype=dtype,
                       device=device)
     b1 = sem.pressure.B(ones)
+    if sem.members > 1:            # the members are copies of one mesh
+      b1 = b1[:b1.numel() // sem.members].contiguous()
     sem._cache[key] = (b1, sem._global_sum(torch.sum(b1).reshape(1)))
   return sem._cache[key]
 
@@ -232,6 +243,15 @@ def _pressure_project_out_nullspace(sem, p, dot_result=None):
   # 1.B(w) / 1.B(1) (:73-78).  B is symmetric, so 1.B(w) = (B 1).w: the
   # vector B 1 is built once and every later call is a dot product.
   b1, total = _pressure_mass_ones(sem, p.dtype, p.device)
+  if sem.members > 1:
+    # every member has its own mean (b1: the weights of one member)
+    if 'ens_project_partials' not in sem._cache:
+      sem._cache['ens_project_partials'] = (
+          torch.empty((sem.members, _lib.SFEM_ENS_GROUPS), dtype=torch.float64,
+                      device=p.device), float(total))
+    partials, total_host = sem._cache['ens_project_partials']
+    return _ops.ens_subtract_weighted_mean(w, b1, total_host, sem.members,
+                                           partials)
   if not sem.is_partitioned:
     # one partition: dot and subtraction as two launches, nothing on the host
     if 'project_partials' not in sem._cache:
@@ -476,6 +496,8 @@ class StokesSEM:
   velocity: StokesVelocity
   pressure: StokesPressure
   velocity_mass_diag: torch.Tensor      # (N, d)
+  # > 1: this is `ensemble(members)` of a single-mesh StokesSEM
+  members: int = 1
   _cache: dict = dataclasses.field(default_factory=dict, repr=False,
                                    compare=False)
 
@@ -515,6 +537,56 @@ class StokesSEM:
   def replace(self, **kw):
     kw.setdefault('_cache', {})
     return dataclasses.replace(self, **kw)
+
+  # --------------------------------------------------------------- ensembles
+  def ensemble(self, members: int) -> 'StokesSEM':
+    """The same operators for an ensemble of `members` flows at once.
+
+    The reference `jax.vmap`s its solver step over an ensemble
+    (niles/train.py:232, :262-264).  Here the ensemble is ONE StokesSEM on
+    `members` disjoint copies of the mesh (`Mesh.replicate`): a batch of
+    fields `(B, N, ...)` is the field `(B N, ...)` of that mesh
+    (`flatten` / `unflatten` are views), every operator -- B, C, D, Dt, E, H,
+    filter -- is the ordinary kernel launched once for all members, and the
+    two solves of `stokes_one_step` run one CG recurrence per member
+    (`linalg/cg_ensemble.py`: own step lengths, stop test and iteration
+    count, results equal to the member-by-member solves).  Everything that
+    takes this object (`navier_stokes_step`, the generator's step) works on
+    the ensemble unchanged.  One partition, no autograd through the solves.
+    """
+    members = int(members)
+    if self.members != 1:
+      raise ValueError('this StokesSEM is an ensemble already')
+    if members == 1:
+      return self
+    if self.is_partitioned:
+      raise NotImplementedError('ensembles of a partitioned mesh')
+    vel, prs = self.velocity, self.pressure
+    vmesh = vel.mesh.replicate(members)
+    pmesh = prs.pspace.mesh.replicate(members)
+    velocity = vel.replace(
+        vspace=FiniteElementSpace.create(mesh=vmesh,
+                                         quadrature=vel.vspace.quadrature),
+        overint_space=FiniteElementSpace.create(
+            mesh=vmesh, quadrature=vel.overint_space.quadrature),
+        interior_mask=vel.interior_mask.repeat(members, 1),
+        diag_qqt=vel.diag_qqt.repeat(members))
+    pressure = prs.replace(pspace=FiniteElementSpace.create(
+        mesh=pmesh, quadrature=prs.pspace.quadrature))
+    return StokesSEM(velocity=velocity, pressure=pressure,
+                     velocity_mass_diag=self.velocity_mass_diag.repeat(
+                         members, 1), members=members)
+
+  def flatten(self, batched: torch.Tensor) -> torch.Tensor:
+    """(B, N, ...) -> (B N, ...): the ensemble's field (a view)."""
+    if batched.shape[0] != self.members:
+      raise ValueError(f'expected {self.members} members; got '
+                       f'{batched.shape[0]}')
+    return batched.reshape((-1,) + tuple(batched.shape[2:]))
+
+  def unflatten(self, field: torch.Tensor) -> torch.Tensor:
+    """(B N, ...) -> (B, N, ...)."""
+    return field.reshape((self.members, -1) + tuple(field.shape[1:]))
 
   # ------------------------------------------------------------- partitions
   @property
@@ -731,7 +803,11 @@ class StokesSEM:
 
     # component-major storage for the Helmholtz solve: every kernel of the CG
     # then works on contiguous component strips (same (N, d) shape for callers)
-    f = layout.component_major(f)
+    # (an ensemble keeps the dense layout: member m is the contiguous block
+    # [m N d, (m + 1) N d) there)
+    ens = {'members': self.members} if self.members > 1 else {}
+    if not ens:
+      f = layout.component_major(f)
     # single-partition solves replay each CG iteration as one HIP graph launch
     # (iterations on small meshes are launch-bound); SFEM_GRAPHS=0 disables it
     graph = (self.velocity.mesh.axis_name is None and
@@ -748,7 +824,8 @@ class StokesSEM:
     if (graph and not diff and self._reduce_fn() is None and
         switches.get('SFEM_GRAPH_REUSE') != '0'):
       ws = self._cache.setdefault('cg_workspaces', {})
-      keep = lambda *key: dict(workspace=ws, key=key + (tol, atol))
+      keep = lambda *key: dict(workspace=ws,
+                               key=key + (tol, atol, self.members))
     else:
       keep = lambda *key: {}
     # (replaying an iteration pays while it is launch-bound; on vectors of
@@ -760,7 +837,7 @@ class StokesSEM:
     small = lambda b: graph and b.numel() <= limit
     u_star, info = _solve(diff, H_, f, M=self.velocity.exchange, tol=tol,
                           atol=atol, graph=small(f),
-                          reduce_fn=self._reduce_fn(),
+                          reduce_fn=self._reduce_fn(), **ens,
                           **(keep('H', beta_k / dt, float(mu))
                              if small(f) else {}))
     if diff:
@@ -794,7 +871,7 @@ class StokesSEM:
                       # iteration cannot hold: sparse products, host logic)
                       graph=small(rhs) and (default_projection or getattr(
                           pressure_preconditioner, 'capturable', False)),
-                      reduce_fn=self._reduce_fn(),
+                      reduce_fn=self._reduce_fn(), **ens,
                       **(keep('E', float(dt), int(time_order),
                               None if default_projection
                               else id(pressure_preconditioner))

@@ -72,6 +72,9 @@ class SchwarzPressurePreconditioner:
   def __init__(self, sem, dt, time_order, coarse_iterations=None,
                coarse_solver='chebyshev'):
     self.sem = sem
+    # an ensemble (`StokesSEM.ensemble`): the local part is element-wise
+    # anyway, the coarse problem is one block per member
+    self.members = sem.members
     vmesh = sem.velocity.mesh
     pmesh = sem.pressure.pspace.mesh
     d = self.d = vmesh.ndim
@@ -186,6 +189,7 @@ class SchwarzPressurePreconditioner:
     E0 = (Gs.multiply(qn[None, :]) @ Gs.T).tocsr()
     E0.sum_duplicates()
     self.coarse_diag = torch.as_tensor(E0.diagonal(), dtype=dtype, device=dev)
+    Es = self.coarse_size = E // self.members
     # rows of equal length (ELL): y = sum_k vals[:, k] x[cols[:, k]] is plain
     # gather / multiply / add, which a HIP graph can hold (`_coarse_solve`)
     width = int(np.diff(E0.indptr).max())
@@ -205,6 +209,10 @@ class SchwarzPressurePreconditioner:
     resid = np.abs(E0 @ np.ones(E)).max() / max(np.abs(E0.diagonal()).max(),
                                                 1e-300)
     self.coarse_singular = bool(resid < 1e-8)
+    if self.members > 1:
+      # the members' blocks are equal: pseudo-inverse / spectrum of the first
+      E0 = E0[:Es, :Es].tocsr()
+      E = Es
     # small coarse problems (a few thousand elements: launch-bound steps): the
     # pseudo-inverse as a dense matrix, one matrix-vector product per apply
     self.E0_pinv = None
@@ -246,17 +254,23 @@ class SchwarzPressurePreconditioner:
     small launch per step, no inner products, exactly linear and symmetric);
     `coarse_solver = 'cg'` keeps the truncated CG of the first version."""
     if self.E0_pinv is not None and self.coarse_solver == 'chebyshev':
+      if self.members > 1:        # (the pseudo-inverse is symmetric)
+        return (b.view(self.members, -1) @ self.E0_pinv).reshape(-1)
       return torch.mv(self.E0_pinv, b)
     if self.coarse_solver == 'cg':
+      if self.members > 1:
+        raise NotImplementedError("coarse_solver='cg' for an ensemble")
       return self._coarse_solve_cg(b)
     from swirl_fem_amd import _ops
+    centre = lambda v: (v.view(self.members, -1) - v.view(
+        self.members, -1).mean(dim=1, keepdim=True)).reshape(-1)
     if self.coarse_singular:
-      b = b - b.mean()
+      b = centre(b)
     lmin, lmax = self.coarse_bounds
     x = _ops.ell_chebyshev(self.E0_cols_t, self.E0_vals_t,
                            1.0 / self.coarse_diag, b.contiguous(),
                            self.coarse_iterations, lmin, lmax)
-    return x - x.mean() if self.coarse_singular else x
+    return centre(x) if self.coarse_singular else x
 
   def _coarse_solve_cg(self, b):
     """The coarse solve as ONE graph launch: its few hundred tiny kernels are

@@ -1,0 +1,166 @@
+"""Ensembles on the device (the reference's `jax.vmap` of its solver step,
+niles/train.py:232, :262-264): B members as B disjoint copies of the mesh,
+operators launched once for all, one CG recurrence per member
+(`StokesSEM.ensemble`, `linalg/cg_ensemble.py`, csrc/sfem_cg_ensemble.hip).
+Every member must equal its own single solve."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device('cuda', 0)
+
+
+def _sem(n=4, order=5, periodic=(0, 1), bcs=None):
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.navier_stokes.navier_stokes import StokesSEM
+  return StokesSEM.create(unit_cube_mesh(n, ndim=2, periodic_dims=periodic),
+                          bcs or {}, order=order, device=DEV)
+
+
+def _fields(sem, B, seed):
+  g = torch.Generator(device=DEV).manual_seed(seed)
+  N = sem.velocity.mesh.num_nodes
+  u = 0.1 * torch.randn(B, N, 2, dtype=torch.float64, device=DEV, generator=g)
+  # consistent on periodic images
+  ex = lambda t: torch.stack([sem.velocity.exchange(v) for v in t])
+  return ex(u) / ex(torch.ones_like(u)), g
+
+
+def test_operators_of_an_ensemble_are_the_members_operators():
+  sem = _sem()
+  B = 3
+  ens = sem.ensemble(B)
+  assert ens.members == B and sem.ensemble(1) is sem
+  u, g = _fields(sem, B, 1)
+  uf = ens.flatten(u)
+  assert uf.shape == (B * sem.velocity.mesh.num_nodes, 2)
+  assert torch.equal(ens.unflatten(uf), u)
+  Np = sem.pressure.pspace.mesh.num_nodes
+  p = torch.randn(B, Np, dtype=torch.float64, device=DEV, generator=g)
+  for name, batched, fn_e, fn_s in [
+      ('C', u, ens.C, sem.C), ('D', u, ens.D, sem.D), ('B', u, ens.B, sem.B),
+      ('Dt', p, ens.Dt, sem.Dt), ('filter', u, ens.filter, sem.filter),
+      ('H', u, lambda v: ens.H(v, 30.0, 0.02), lambda v: sem.H(v, 30.0, 0.02)),
+      ('E', p, lambda v: ens.E(v, dt=1e-2, time_order=2),
+       lambda v: sem.E(v, dt=1e-2, time_order=2))]:
+    got = ens.unflatten(fn_e(ens.flatten(batched)))
+    for b in range(B):
+      want = fn_s(batched[b])
+      scale = max(float(want.abs().max()), 1e-30)
+      assert float((got[b] - want).abs().max()) <= 1e-12 * scale, (name, b)
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_ensemble_cg_is_one_recurrence_per_member(graph):
+  """Members of very different difficulty: each stops at its own iteration
+  with its own single-solve iterate."""
+  from swirl_fem_amd.linalg.cg import cg
+  from swirl_fem_amd.linalg.cg_ensemble import cg_ensemble
+  sem = _sem(n=5, order=6)
+  B = 4
+  ens = sem.ensemble(B)
+  u, _ = _fields(sem, B, 2)
+  rhs = torch.stack([sem.B(v) for v in u])
+  rhs[1] *= 1e-3                      # relative stop: same count, scaled x
+  rhs[2] = 0.0                        # converged before the first iteration
+  rhs[3] = sem.B(torch.ones_like(u[3]))        # smooth: a handful of iterations
+  H_e = lambda v: ens.H(v, 25.0, 0.01)
+  H_s = lambda v: sem.H(v, 25.0, 0.01)
+  x, info = cg_ensemble(H_e, ens.flatten(rhs), B, M=ens.velocity.exchange,
+                        tol=1e-10, graph=graph, check_every=4)
+  x = ens.unflatten(x)
+  assert info['status'] == 'converged'
+  counts = []
+  for b in range(B):
+    xb, ib = cg(H_s, rhs[b], M=sem.velocity.exchange, tol=1e-10)
+    counts.append(ib['num_iterations'])
+    assert abs(info['member_iterations'][b] - ib['num_iterations']) <= 1, b
+    scale = max(float(xb.abs().max()), 1e-30)
+    assert float((x[b] - xb).abs().max()) <= 1e-9 * scale, b
+  assert info['member_iterations'][2] == 0
+  assert len(set(counts)) > 1         # the members did stop at different counts
+  assert info['num_iterations'] == max(info['member_iterations'])
+  # a second solve (the inner products are fixed-order sums; the operator's
+  # scatter still adds in arrival order)
+  x2, info2 = cg_ensemble(H_e, ens.flatten(rhs), B, M=ens.velocity.exchange,
+                          tol=1e-10, graph=graph, check_every=4)
+  assert float((ens.unflatten(x2) - x).abs().max()) <= 1e-11 * float(
+      x.abs().max())
+  assert all(abs(a - b) <= 1 for a, b in zip(info2['member_iterations'],
+                                             info['member_iterations']))
+
+
+@pytest.mark.parametrize('pc', [None, 'schwarz'])
+def test_ensemble_step_equals_the_members_steps(pc):
+  """Three flows, three steps of the Kolmogorov generator's step: every
+  member of the ensemble step equals its own single step."""
+  from swirl_fem_amd.examples.navier_stokes_driver import navier_stokes_step
+  from swirl_fem_amd.niles.datagen import datagen
+  sem = _sem(n=6, order=5)
+  B = 3
+  ens = sem.ensemble(B)
+  x = sem.velocity.mesh.node_coords
+  amp = [1.0, 0.4, 1.7]
+  u0 = torch.stack([a * datagen.u_init_fn(x) for a in amp])
+  Np = sem.pressure.pspace.mesh.num_nodes
+  p0 = torch.zeros(B, Np, dtype=torch.float64, device=DEV)
+  kw = dict(reynolds=200.0, dt=2e-3, time_order=2, tol=1e-11, atol=0.0,
+            pressure_preconditioner=pc)
+
+  def run(s, u, p, steps=3):
+    us, ps = (u, u), (p, p)
+    c = s.C(u)
+    Cus = (c, c)
+    its = []
+    for _ in range(steps):
+      f = datagen.forcing(s.velocity.mesh.node_coords, us[-1], 0.1)
+      un, pn, cn, aux = navier_stokes_step(s, us, ps, Cus, forcing=f, **kw)
+      us, ps, Cus = us[1:] + (un,), ps[1:] + (pn,), Cus[1:] + (cn,)
+      its.append(aux)
+    return us[-1], ps[-1], its
+
+  ue, pe, aux_e = run(ens, ens.flatten(u0), ens.flatten(p0))
+  ue, pe = ens.unflatten(ue), ens.unflatten(pe)
+  for b in range(B):
+    ub, pb, aux_b = run(sem, u0[b], p0[b])
+    assert float((ue[b] - ub).abs().max()) <= 1e-9 * float(ub.abs().max()), b
+    assert float((pe[b] - pb).abs().max()) <= 1e-8 * max(
+        1.0, float(pb.abs().max())), b
+    for k in range(3):
+      for which in ('u_star_info', 'dp_info'):
+        got = aux_e[k][which]['member_iterations'][b]
+        want = aux_b[k][which]['num_iterations']
+        assert abs(got - want) <= 2, (b, k, which, got, want)
+
+
+def test_ensemble_with_dirichlet_walls():
+  """The lid-driven cavity as an ensemble of two lids."""
+  from swirl_fem_amd.examples.navier_stokes_driver import navier_stokes_step
+  from swirl_fem_amd.navier_stokes.navier_stokes import BCType
+  sem = _sem(n=4, order=5, periodic=(),
+             bcs={'boundary': (BCType.DIRICHLET, 0.0)})
+  B = 2
+  ens = sem.ensemble(B)
+  x = sem.velocity.mesh.node_coords
+  lid = (x[:, 1] > 1.0 - 1e-12).to(x.dtype)
+  prof = torch.stack([lid * 16 * x[:, 0] ** 2 * (1 - x[:, 0]) ** 2,
+                      torch.zeros_like(lid)], dim=-1)
+  ub = torch.stack([prof, -0.5 * prof])
+  Np = sem.pressure.pspace.mesh.num_nodes
+  p0 = torch.zeros(B, Np, dtype=torch.float64, device=DEV)
+  kw = dict(reynolds=100.0, dt=1e-3, time_order=2, tol=1e-11, atol=0.0)
+
+  def one(s, u, p, u_b):
+    c = s.C(u)
+    return navier_stokes_step(s, (u, u), (p, p), (c, c), u_boundary=u_b,
+                              **kw)[:2]
+
+  ue, pe = one(ens, ens.flatten(ub), ens.flatten(p0), ens.flatten(ub))
+  ue, pe = ens.unflatten(ue), ens.unflatten(pe)
+  for b in range(B):
+    u1, p1 = one(sem, ub[b], p0[b], ub[b])
+    assert float((ue[b] - u1).abs().max()) <= 1e-9 * float(u1.abs().max())
+    assert float((pe[b] - p1).abs().max()) <= 1e-8 * max(
+        1.0, float(p1.abs().max()))

@@ -768,3 +768,39 @@ def test_every_environment_switch_is_registered_and_documented():
   finally:
     del os.environ['SFEM_BOX']
   assert switches.enabled('SFEM_BOX') and not switches.enabled('SFEM_MFMA')
+
+
+def test_mesh_replicate_is_disjoint_copies():
+  """`Mesh.replicate` (ensembles, the reference's vmap over niles/train.py:232):
+  copy b owns nodes [b N, (b + 1) N) and elements [b E, (b + 1) E); periodic
+  images stay inside their copy."""
+  import torch
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.core.interpolation import Nodes1D, NodeType
+  from swirl_fem_amd.core.mesh_refiner import refine_premesh
+  pm = unit_cube_mesh(3, ndim=2, periodic_dims=(0,))
+  grid = Nodes1D.create(num_points=4, node_type=NodeType.GAUSS_LOBATTO_LEGENDRE)
+  m = refine_premesh(pm, gridpoints_1d=grid).finalize(None, device='cpu')
+  B, N, E = 3, m.num_nodes, m.num_elements
+  r = m.replicate(B)
+  assert m.replicate(1) is m
+  assert (r.num_nodes, r.num_elements) == (B * N, B * E)
+  for b in range(B):
+    assert torch.equal(r.elements[b * E:(b + 1) * E], m.elements + b * N)
+    assert torch.equal(r.node_coords[b * N:(b + 1) * N], m.node_coords)
+    assert torch.equal(r.node_indices[b * N:(b + 1) * N], m.node_indices + b * N)
+    for k, v in m.physical_masks.items():
+      assert torch.equal(r.physical_masks[k][b * N:(b + 1) * N], v)
+  G = m.exchange_gather_indices.numel()
+  assert G > 0 and r.exchange_gather_indices.numel() == B * G
+  ui, ri = np.asarray(m.exchange_unique_indices), np.asarray(
+      r.exchange_unique_indices)
+  width = int(ui.max()) + 1
+  for b in range(B):
+    assert torch.equal(r.exchange_gather_indices[b * G:(b + 1) * G],
+                       m.exchange_gather_indices + b * N)
+    assert np.array_equal(ri[b * G:(b + 1) * G], ui + b * width)
+  # classes of different copies never meet
+  assert len(np.unique(ri)) == B * len(np.unique(ui))
+  with pytest.raises(ValueError):
+    m.replicate(0)
