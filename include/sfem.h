@@ -722,6 +722,23 @@ int sfem_ens_close(double* scalars, const double* partials, int members,
 int sfem_ens_update_xp(void* x, void* p, const void* z, int64_t len,
                        int members, const double* scalars, int dtype,
                        sfem_stream_t stream);
+/* The same iteration for M r = r - (w . r / total) 1 per member (w: ONE
+ * member's weights, len values) without storing z = M r, as
+ * sfem_cg_update_r_mean / sfem_cg_update_xp_mean do for the single solve:
+ *     Ap = A p;  sfem_ens_dot(p, Ap, 0);  sfem_ens_update_r_mean;
+ *     sfem_ens_close_mean;  sfem_ens_update_xp_mean
+ * `sums`: members x 3 x SFEM_ENS_GROUPS doubles (r.r, 1.r, w.r); the mean c of
+ * the iteration is left in scalars[12].                                      */
+int sfem_ens_update_r_mean(void* r, const void* ap, const void* w, int64_t len,
+                           int members, const double* scalars,
+                           const double* partials, double* sums, int dtype,
+                           sfem_stream_t stream);
+int sfem_ens_close_mean(double* scalars, const double* partials,
+                        const double* sums, double total, int members,
+                        double maxiter, sfem_stream_t stream);
+int sfem_ens_update_xp_mean(void* x, void* p, const void* r, int64_t len,
+                            int members, const double* scalars, int dtype,
+                            sfem_stream_t stream);
 /* out_m = w_m - (b . w_m / total) 1 for every member m (b: one member's
  * weights, len values; partials: members x SFEM_ENS_GROUPS doubles): the mean
  * projection of the pressure solve (navier_stokes.py:73-78) per member.      */

@@ -140,6 +140,11 @@ SIGNATURES = {
     'sfem_ens_close': [c_ptr, c_ptr, c_i32, c_dbl, c_ptr],
     'sfem_ens_update_xp': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32,
                            c_ptr],
+    'sfem_ens_update_r_mean': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
+                               c_ptr, c_i32, c_ptr],
+    'sfem_ens_close_mean': [c_ptr, c_ptr, c_ptr, c_dbl, c_i32, c_dbl, c_ptr],
+    'sfem_ens_update_xp_mean': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr,
+                                c_i32, c_ptr],
     'sfem_ens_subtract_weighted_mean': [c_ptr, c_ptr, c_dbl, c_ptr, c_ptr,
                                         c_i64, c_i32, c_i32, c_ptr],
     'sfem_fold_layers': [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr],

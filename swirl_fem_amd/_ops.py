@@ -787,6 +787,33 @@ def ens_update_xp(x, p, z, members, scalars):
         _stream(dev)), 'sfem_ens_update_xp')
 
 
+def ens_update_r_mean(r, ap, w, members, scalars, partials, sums):
+  dev, ln = _ens_check(members, r, ap)
+  if w.numel() != ln or w.dtype != r.dtype or not w.is_contiguous():
+    raise ValueError('ens_update_r_mean: weights of one member')
+  _dev(w, sums)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_update_r_mean(
+        _ptr(r), _ptr(ap), _ptr(w), ln, members, _ptr(scalars), _ptr(partials),
+        _ptr(sums), _dtype_code(r), _stream(dev)), 'sfem_ens_update_r_mean')
+
+
+def ens_close_mean(scalars, partials, sums, total, members, maxiter):
+  dev = _dev(scalars, partials, sums)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_close_mean(
+        _ptr(scalars), _ptr(partials), _ptr(sums), float(total), members,
+        float(maxiter), _stream(dev)), 'sfem_ens_close_mean')
+
+
+def ens_update_xp_mean(x, p, r, members, scalars):
+  dev, ln = _ens_check(members, x, p, r)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_ens_update_xp_mean(
+        _ptr(x), _ptr(p), _ptr(r), ln, members, _ptr(scalars), _dtype_code(x),
+        _stream(dev)), 'sfem_ens_update_xp_mean')
+
+
 def ens_subtract_weighted_mean(w, b, total, members, partials, out=None):
   """out_m = w_m - (b . w_m / total) 1 for every member (b: one member)."""
   w, b = w.contiguous(), b.contiguous()

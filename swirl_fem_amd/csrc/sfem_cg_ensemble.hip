@@ -226,6 +226,117 @@ ens_subtract_mean_kernel(const T* __restrict__ w, T* __restrict__ out,
     om[i] = wm[i] - c;
 }
 
+// ---- the pair for M r = r - (w . r / total) 1 per member (the mean
+// projection of the pressure solve, navier_stokes.py:73-78) without storing
+// z = M r: the r update also sums r.r, 1.r and w.r (sums[m][0..3][g]); the
+// closing kernel forms c = w.r / total and gamma_new = r.r - c 1.r; the x / p
+// update uses z = r - c on the fly.  Four launches per iteration besides the
+// operator instead of seven (same arithmetic as sfem_cg_update_r_mean /
+// sfem_cg_update_xp_mean of the single solve).
+template <typename T>
+__global__ void __launch_bounds__(ENS_SUM_BLOCK)
+ens_update_r_mean_kernel(T* __restrict__ r, const T* __restrict__ ap,
+                         const T* __restrict__ w, int64_t len,
+                         const double* __restrict__ scalars,
+                         const double* __restrict__ partials,
+                         double* __restrict__ sums) {
+  const int m = blockIdx.y, g = blockIdx.x;
+  const double* s = scalars + (int64_t)m * ENS_NS;
+  if (s[7] != 0.0) return;                 // (uniform over the workgroup)
+  const double pap = ens_total(partials, m, 0);
+  if (ens_bad_pap(pap)) return;
+  const T alpha = (T)(s[0] / pap);
+  const int64_t chunk = (len + ENS_G - 1) / ENS_G;
+  const int64_t lo = (int64_t)g * chunk;
+  const int64_t hi = lo + chunk < len ? lo + chunk : len;
+  T* rm = r + (int64_t)m * len;
+  const T* am = ap + (int64_t)m * len;
+  double rr = 0.0, sr = 0.0, wr = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += ENS_SUM_BLOCK) {
+    const T v = rm[i] - alpha * am[i];
+    rm[i] = v;
+    rr += (double)v * (double)v;
+    sr += (double)v;
+    wr += (double)w[i] * (double)v;
+  }
+  rr = ens_block_sum(rr);
+  __syncthreads();
+  sr = ens_block_sum(sr);
+  __syncthreads();
+  wr = ens_block_sum(wr);
+  if (threadIdx.x == 0) {
+    double* o = sums + (int64_t)m * 3 * ENS_G + g;
+    o[0] = rr;
+    o[ENS_G] = sr;
+    o[2 * ENS_G] = wr;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ens_close_mean_kernel(double* __restrict__ scalars,
+                      const double* __restrict__ partials,
+                      const double* __restrict__ sums, double total,
+                      int members, double maxiter) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= members) return;
+  double* s = scalars + (int64_t)m * ENS_NS;
+  s[9] = 0.0;
+  if (s[7] != 0.0) return;
+  const double pap = ens_total(partials, m, 0);
+  s[1] = pap;
+  if (ens_bad_pap(pap)) {
+    s[10] = SFEM_CG_STATUS_BAD_PAP;
+    s[7] = 1.0;
+    return;
+  }
+  const double* q = sums + (int64_t)m * 3 * ENS_G;
+  double rr = 0.0, sr = 0.0, wr = 0.0;
+  for (int g = 0; g < ENS_G; ++g) {
+    rr += q[g];
+    sr += q[ENS_G + g];
+    wr += q[2 * ENS_G + g];
+  }
+  const double c = wr / total;
+  const double g = rr - c * sr;
+  s[12] = c;
+  s[3] = s[0] / pap;
+  s[4] = g / s[0];
+  s[0] = g;
+  s[8] += 1.0;
+  s[9] = 1.0;
+  if (ens_bad_gamma(g)) {
+    s[10] = SFEM_CG_STATUS_BAD_GAMMA;
+    s[7] = 1.0;
+  } else if (!(g > s[6])) {
+    s[10] = SFEM_CG_STATUS_CONVERGED;
+    s[7] = 1.0;
+  } else if (s[8] >= maxiter) {
+    s[10] = SFEM_CG_STATUS_MAXITER;
+    s[7] = 1.0;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+ens_update_xp_mean_kernel(T* __restrict__ x, T* __restrict__ p,
+                          const T* __restrict__ r, int64_t len,
+                          const double* __restrict__ scalars) {
+  const int m = blockIdx.y;
+  const double* s = scalars + (int64_t)m * ENS_NS;
+  if (s[9] == 0.0) return;
+  const T alpha = (T)s[3], beta = (T)s[4], c = (T)s[12];
+  T* xm = x + (int64_t)m * len;
+  T* pm = p + (int64_t)m * len;
+  const T* rm = r + (int64_t)m * len;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len;
+       i += stride) {
+    const T pv = pm[i];
+    xm[i] += alpha * pv;
+    pm[i] = (rm[i] - c) + beta * pv;
+  }
+}
+
 inline unsigned ens_blocks(int64_t len) {
   const int64_t b = (len + 1023) / 1024;          // four values per thread
   return (unsigned)(b < 1 ? 1 : (b > 512 ? 512 : b));
@@ -322,6 +433,65 @@ extern "C" int sfem_ens_update_xp(void* x, void* p, const void* z, int64_t len,
     hipLaunchKernelGGL(ens_update_xp_kernel<float>, grid, dim3(256), 0,
                        as_stream(stream), (float*)x, (float*)p,
                        (const float*)z, len, scalars);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+extern "C" int sfem_ens_update_r_mean(void* r, const void* ap, const void* w,
+                                      int64_t len, int members,
+                                      const double* scalars,
+                                      const double* partials, double* sums,
+                                      int dtype, sfem_stream_t stream) {
+  SFEM_ENS_CHECK("sfem_ens_update_r_mean");
+  if (len == 0) return SFEM_OK;
+  SFEM_REQUIRE(r && ap && w && scalars && partials && sums,
+               "sfem_ens_update_r_mean: null pointer");
+  const dim3 grid(ENS_G, (unsigned)members);
+  if (dtype == SFEM_F64)
+    hipLaunchKernelGGL(ens_update_r_mean_kernel<double>, grid,
+                       dim3(ENS_SUM_BLOCK), 0, as_stream(stream), (double*)r,
+                       (const double*)ap, (const double*)w, len, scalars,
+                       partials, sums);
+  else
+    hipLaunchKernelGGL(ens_update_r_mean_kernel<float>, grid,
+                       dim3(ENS_SUM_BLOCK), 0, as_stream(stream), (float*)r,
+                       (const float*)ap, (const float*)w, len, scalars,
+                       partials, sums);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+extern "C" int sfem_ens_close_mean(double* scalars, const double* partials,
+                                   const double* sums, double total,
+                                   int members, double maxiter,
+                                   sfem_stream_t stream) {
+  SFEM_REQUIRE(scalars && partials && sums && total != 0.0 && members >= 1 &&
+                   members <= SFEM_ENS_MAX_MEMBERS,
+               "sfem_ens_close_mean: null pointer, total = 0 or bad member "
+               "count");
+  hipLaunchKernelGGL(ens_close_mean_kernel, dim3((members + 255) / 256),
+                     dim3(256), 0, as_stream(stream), scalars, partials, sums,
+                     total, members, maxiter);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+extern "C" int sfem_ens_update_xp_mean(void* x, void* p, const void* r,
+                                       int64_t len, int members,
+                                       const double* scalars, int dtype,
+                                       sfem_stream_t stream) {
+  SFEM_ENS_CHECK("sfem_ens_update_xp_mean");
+  if (len == 0) return SFEM_OK;
+  SFEM_REQUIRE(x && p && r && scalars, "sfem_ens_update_xp_mean: null pointer");
+  const dim3 grid(ens_blocks(len), (unsigned)members);
+  if (dtype == SFEM_F64)
+    hipLaunchKernelGGL(ens_update_xp_mean_kernel<double>, grid, dim3(256), 0,
+                       as_stream(stream), (double*)x, (double*)p,
+                       (const double*)r, len, scalars);
+  else
+    hipLaunchKernelGGL(ens_update_xp_mean_kernel<float>, grid, dim3(256), 0,
+                       as_stream(stream), (float*)x, (float*)p,
+                       (const float*)r, len, scalars);
   SFEM_LAUNCH_CHECK();
   return SFEM_OK;
 }

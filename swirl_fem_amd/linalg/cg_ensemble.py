@@ -13,7 +13,7 @@ owns the contiguous rows [m N, (m + 1) N), `A` and `M` are the ordinary
 operators of that mesh (linear, member by member) and serve all members in
 one launch each.  The recurrence runs per member inside the `sfem_ens_*`
 kernels (csrc/sfem_cg_ensemble.hip): an iteration is the same seven launches
-whatever B is, members that have stopped become no-ops, and each member's
+(four with the mean projection of the pressure solve folded in) whatever B is, members that have stopped become no-ops, and each member's
 iterates are those of its own single solve (inner products: stored partial
 sums added in a fixed order -- no atomics, nothing to clear).
 """
@@ -24,7 +24,7 @@ import gc
 
 import torch
 
-from swirl_fem_amd import _lib, _ops
+from swirl_fem_amd import _lib, _ops, switches
 
 MAX_KEPT_RUNNERS = 8
 
@@ -55,6 +55,17 @@ class EnsembleCGRunner:
     self.x = torch.zeros(self.shape, dtype=b.dtype, device=dev)
     self.r = torch.empty_like(self.x)
     self.p = torch.empty_like(self.x)
+    # M r = r - (w . r / total) 1 per member folded into the vector updates
+    # (`sfem_ens_update_r_mean`): z = M r is never stored
+    self.mean = None
+    probe = getattr(M, 'ensemble_mean_projection', None)
+    found = probe() if (probe is not None and b.dim() == 1 and
+                        switches.get('SFEM_FUSED_MEAN') != '0') else None
+    if found is not None:
+      w, total = found
+      self.mean = (w.to(b.dtype).contiguous(), float(total),
+                   torch.zeros((members, 3, _lib.SFEM_ENS_GROUPS),
+                               dtype=torch.float64, device=dev))
     self.issued = 0
     self._graph = None
     self._capture_failed = False
@@ -95,6 +106,15 @@ class EnsembleCGRunner:
     B = self.members
     Ap = self._dense(self.A(self.p))
     _ops.ens_dot(self.p, Ap, B, self.partials, 0)
+    if self.mean is not None:
+      w, total, sums = self.mean
+      _ops.ens_update_r_mean(self.r, Ap, w, B, self.scalars, self.partials,
+                             sums)
+      _ops.ens_close_mean(self.scalars, self.partials, sums, total, B,
+                          self.maxiter)
+      _ops.ens_update_xp_mean(self.x, self.p, self.r, B, self.scalars)
+      self.issued += 1
+      return
     _ops.ens_update_r(self.r, Ap, B, self.scalars, self.partials)
     z = self.r if self.M is None else self._dense(self.M(self.r))
     _ops.ens_dot(self.r, z, B, self.partials, 1)

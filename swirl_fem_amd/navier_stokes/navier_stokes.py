@@ -152,6 +152,17 @@ class _NullspaceProjection:
   def _apply_with_dot(self, r, scalars, slot):
     return _pressure_project_out_nullspace(self.sem, r, (scalars, slot))
 
+  def ensemble_mean_projection(self):
+    """`mean_projection` for an ensemble: (w of ONE member, its total); every
+    member has its own mean (`linalg/cg_ensemble.py`)."""
+    sem = self.sem
+    pmesh = sem.pressure.pspace.mesh
+    gi = pmesh.exchange_gather_indices
+    if sem.members == 1 or (gi is not None and gi.numel() != 0):
+      return None
+    b1, total = _pressure_mass_ones(sem, pmesh.dtype, pmesh.device)
+    return b1, float(total)
+
   def mean_projection(self):
     """(w, total) when this preconditioner IS r -> r - (w . r / total) 1 (one
     partition, pressure nodes inside their elements: QQ^T is the identity), so

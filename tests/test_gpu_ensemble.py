@@ -92,10 +92,15 @@ def test_ensemble_cg_is_one_recurrence_per_member(graph):
                                              info['member_iterations']))
 
 
-@pytest.mark.parametrize('pc', [None, 'schwarz'])
-def test_ensemble_step_equals_the_members_steps(pc):
+@pytest.mark.parametrize('pc', [None, 'unfused', 'schwarz'])
+def test_ensemble_step_equals_the_members_steps(pc, monkeypatch):
   """Three flows, three steps of the Kolmogorov generator's step: every
-  member of the ensemble step equals its own single step."""
+  member of the ensemble step equals its own single step (default: the mean
+  projection of the pressure solve folded into the vector updates, per member;
+  'unfused': z = M r stored)."""
+  if pc == 'unfused':
+    monkeypatch.setenv('SFEM_FUSED_MEAN', '0')
+    pc = None
   from swirl_fem_amd.examples.navier_stokes_driver import navier_stokes_step
   from swirl_fem_amd.niles.datagen import datagen
   sem = _sem(n=6, order=5)
