@@ -7,6 +7,13 @@ field per call (an ensemble shares nothing but the operator data, and every
 solve has its own iteration count), so the batch axis is walked on the host:
 same results as a vmapped call, every item on the same stream, autograd
 through each item (`linalg.cg.symmetric_solve`, `core/autodiff.py`).
+
+For the solver step itself there is a batched path that needs no host loop:
+`StokesSEM.ensemble(B)` (navier_stokes/navier_stokes.py) runs the B members as
+one mesh of B copies -- operators launched once for all members, one CG
+recurrence per member in the kernels (`linalg/cg_ensemble.py`) -- at a third
+of this loop's cost for 8 members of the Kolmogorov generator.  It has no
+autograd through its solves; this `vmap` does.
 """
 
 from __future__ import annotations
