@@ -12,8 +12,8 @@ For the solver step itself there is a batched path that needs no host loop:
 `StokesSEM.ensemble(B)` (navier_stokes/navier_stokes.py) runs the B members as
 one mesh of B copies -- operators launched once for all members, one CG
 recurrence per member in the kernels (`linalg/cg_ensemble.py`) -- at a third
-of this loop's cost for 8 members of the Kolmogorov generator.  It has no
-autograd through its solves; this `vmap` does.
+of this loop's cost for 8 members of the Kolmogorov generator, autograd
+included.  This `vmap` stays for arbitrary functions of one member.
 """
 
 from __future__ import annotations

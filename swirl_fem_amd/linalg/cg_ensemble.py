@@ -215,3 +215,32 @@ def cg_ensemble(A, b, members, x0=None, *, tol=1e-5, atol=0.0, maxiter=None,
                   'solution to the requested tolerance', RuntimeWarning,
                   stacklevel=2)
   return (run.x.clone() if reuse else run.x), info
+
+
+class _EnsembleSymmetricSolve(torch.autograd.Function):
+  """x_m = A^-1 b_m for every member, with the adjoint solved by the same
+  routine (A symmetric): see `linalg.cg.symmetric_solve`."""
+
+  @staticmethod
+  def forward(ctx, b, A, members, kwargs, info_out):
+    x, info = cg_ensemble(A, b.detach(), members, **kwargs)
+    if info_out is not None:
+      info_out.update(info)
+    ctx.A, ctx.members, ctx.kwargs = A, members, kwargs
+    return x
+
+  @staticmethod
+  def backward(ctx, grad_x):
+    kwargs = dict(ctx.kwargs)
+    kwargs.pop('x0', None)         # (a start for b says nothing about g)
+    grad_b, _ = cg_ensemble(ctx.A, grad_x.detach().contiguous(), ctx.members,
+                            **kwargs)
+    return grad_b, None, None, None, None
+
+
+def symmetric_solve_ensemble(A, b, members, info_out=None, **kwargs):
+  """`cg_ensemble(A, b, members, **kwargs)[0]` that autograd differentiates
+  with respect to `b` (one more ensemble solve for the cotangent: what
+  `jax.vmap` of `lax.custom_linear_solve(symmetric=True)` does for the
+  reference's solves, navier_stokes/navier_stokes.py:436-452)."""
+  return _EnsembleSymmetricSolve.apply(b, A, members, kwargs, info_out)

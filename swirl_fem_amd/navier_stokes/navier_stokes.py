@@ -103,11 +103,14 @@ def _solve(differentiable, A, b, **kwargs):
   if members > 1:
     # an ensemble on the replicated mesh: one recurrence per member
     # (linalg/cg_ensemble.py)
-    if differentiable or kwargs.pop('reduce_fn', None) is not None:
-      raise NotImplementedError('ensembles: one partition, no autograd '
-                                '(differentiate member by member)')
-    from swirl_fem_amd.linalg.cg_ensemble import cg_ensemble
-    return cg_ensemble(A, b, members, **kwargs)
+    if kwargs.pop('reduce_fn', None) is not None:
+      raise NotImplementedError('ensembles of a partitioned mesh')
+    from swirl_fem_amd.linalg import cg_ensemble as ens
+    if not differentiable:
+      return ens.cg_ensemble(A, b, members, **kwargs)
+    info = {}
+    x = ens.symmetric_solve_ensemble(A, b, members, info_out=info, **kwargs)
+    return x, info
   if not differentiable:
     return cg(A, b, **kwargs)
   info = {}
@@ -563,7 +566,8 @@ class StokesSEM:
     (`linalg/cg_ensemble.py`: own step lengths, stop test and iteration
     count, results equal to the member-by-member solves).  Everything that
     takes this object (`navier_stokes_step`, the generator's step) works on
-    the ensemble unchanged.  One partition, no autograd through the solves.
+    the ensemble unchanged, autograd included (the cotangent of a solve is
+    one more ensemble solve).  One partition.
     """
     members = int(members)
     if self.members != 1:

@@ -169,3 +169,38 @@ def test_ensemble_with_dirichlet_walls():
     assert float((ue[b] - u1).abs().max()) <= 1e-9 * float(u1.abs().max())
     assert float((pe[b] - p1).abs().max()) <= 1e-8 * max(
         1.0, float(p1.abs().max()))
+
+
+def test_gradients_through_an_ensemble_step():
+  """d/d forcing of a functional of the ensemble step: member b only sees
+  forcing[b], and its gradient is the single step's (the reference vmaps a
+  differentiable step, niles/train.py:262-264)."""
+  from swirl_fem_amd.examples.navier_stokes_driver import navier_stokes_step
+  sem = _sem(n=3, order=4)
+  B = 3
+  ens = sem.ensemble(B)
+  u0, g = _fields(sem, B, 5)
+  N = sem.velocity.mesh.num_nodes
+  Np = sem.pressure.pspace.mesh.num_nodes
+  p0 = torch.zeros(B, Np, dtype=torch.float64, device=DEV)
+  forcing = 0.05 * torch.randn(B, N, 2, dtype=torch.float64, device=DEV,
+                               generator=g)
+  w = torch.randn(B, N, 2, dtype=torch.float64, device=DEV, generator=g)
+  kw = dict(reynolds=50.0, dt=1e-2, time_order=2, tol=1e-12, atol=0.0)
+
+  def one(s, u, p, f):
+    cu = s.C(u)
+    return navier_stokes_step(s, (u, u), (p, p), (cu, cu), forcing=f, **kw)[0]
+
+  fe = forcing.clone().requires_grad_(True)
+  ue = ens.unflatten(one(ens, ens.flatten(u0), ens.flatten(p0),
+                         ens.flatten(fe)))
+  (ue * w).sum().backward()
+  for b in range(B):
+    fb = forcing[b].clone().requires_grad_(True)
+    ub = one(sem, u0[b], p0[b], fb)
+    assert float((ue[b].detach() - ub.detach()).abs().max()) <= 1e-10 * float(
+        ub.detach().abs().max())
+    (ub * w[b]).sum().backward()
+    assert float((fe.grad[b] - fb.grad).abs().max()) <= 1e-9 * float(
+        fb.grad.abs().max()), b
