@@ -204,3 +204,56 @@ def test_gradients_through_an_ensemble_step():
     (ub * w[b]).sum().backward()
     assert float((fe.grad[b] - fb.grad).abs().max()) <= 1e-9 * float(
         fb.grad.abs().max()), b
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_ensemble_kernels_against_a_host_recurrence(dtype):
+  """The `sfem_ens_*` kernels on diagonal systems (A = diag(d), the same for
+  every member) against the recurrence of linalg/cg.py:60-97 written out on the
+  host in float64: per-member alpha, beta, stop test and counts; float32
+  vectors with float64 scalars."""
+  from swirl_fem_amd.linalg.cg_ensemble import cg_ensemble
+  rng = np.random.default_rng(7)
+  B, n = 5, 3001                      # (not a multiple of the group count)
+  d = np.linspace(1.0, 50.0, n) ** 1.5
+  rhs = rng.standard_normal((B, n))
+  rhs[1] *= 1e4
+  rhs[3] = 0.0
+  rhs[4, 10:] = 0.0                   # few distinct eigenvalues: stops early
+  tol = 1e-9 if dtype == torch.float64 else 1e-4
+  dd = torch.as_tensor(d, dtype=dtype, device=DEV).repeat(B)
+  b = torch.as_tensor(rhs, dtype=dtype, device=DEV).reshape(-1)
+  x, info = cg_ensemble(lambda v: dd * v, b, B, tol=tol, maxiter=400,
+                        check_every=7)
+  x = x.reshape(B, n).double().cpu().numpy()
+  d32 = dd[:n].double().cpu().numpy()
+  r32 = b.reshape(B, n).double().cpu().numpy()
+  for m in range(B):
+    xs = np.zeros(n)
+    r = r32[m].copy()
+    p = r.copy()
+    gamma = r @ r
+    thresh = tol * tol * (r32[m] @ r32[m])
+    k = 0
+    while gamma > thresh and k < 400:
+      ap = d32 * p
+      alpha = gamma / (p @ ap)
+      xs += alpha * p
+      r -= alpha * ap
+      gnew = r @ r
+      p = r + (gnew / gamma) * p
+      gamma = gnew
+      k += 1
+    slack = 0 if dtype == torch.float64 else 2
+    assert abs(info['member_iterations'][m] - k) <= slack, (m, k, info)
+    scale = max(np.abs(xs).max(), 1e-300)
+    err = np.abs(x[m] - xs).max() / scale
+    assert err <= (1e-10 if dtype == torch.float64 else 2e-3), (m, err)
+  assert info['member_iterations'][3] == 0
+  assert info['member_status'] == ['converged'] * B
+  # maxiter: every running member stops there and says so
+  x2, info2 = cg_ensemble(lambda v: dd * v, b, B, tol=1e-30, maxiter=5)
+  assert info2['member_iterations'][0] == 5
+  assert info2['member_status'][0] == 'maxiter'
+  assert info2['member_status'][3] == 'converged'
+  assert info2['status'] == 'maxiter'
