@@ -28,6 +28,7 @@ SFEM_MAX_LAYERS = 15
 SFEM_FOLD_GROUPS = 256
 SFEM_LAYER_CHUNK = 512
 SFEM_CG_LAZY_MAX = 8
+SFEM_IDX_MASK = 0x3FFFFFFF   # node id field of an encoded index (and its pad value)
 SFEM_ENS_NSCALARS = 16   # per member: the named scalars of the single solve
 SFEM_ENS_GROUPS = 32      # stored partial sums per member and inner product
 SFEM_ENS_MAX_MEMBERS = 4096

@@ -181,6 +181,23 @@ def exchange_local(u, gather_indices, unique_indices, inplace=False):
   return out
 
 
+def exchange_classes_(u, members, offsets, num_classes):
+  """In place: every member position of a class receives the sum over the
+  class (`sfem_exchange_classes`; members / offsets: int32 CSR on the device)."""
+  if num_classes == 0:
+    return u
+  cm = is_component_major(u)
+  if not (cm or u.is_contiguous()):
+    raise ValueError('exchange_classes_: dense field expected')
+  dev = _dev(u.movedim(-1, 0) if cm else u, members, offsets)
+  ncomp, ns, cs = _node_view(u)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_exchange_classes(
+        _ptr(u), _ptr(members), _ptr(offsets), int(num_classes), ncomp, ns, cs,
+        _dtype_code(u), _stream(dev)), 'sfem_exchange_classes')
+  return u
+
+
 def exchange_local_atomic(u, gather_indices, unique_indices):
   """The same QQ^T through `sfem_exchange_local` (segment sums by atomics into
   a workspace, then expansion): the C-ABI's out-of-place form."""

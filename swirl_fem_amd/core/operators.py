@@ -911,6 +911,8 @@ class StokesDivGrad:
   # 3D, P = 6..8: `csrc/sfem_stokes_facet.h`), or None
   facet_parts: list | None = None
   _div_parts: list | None = None      # what `div` launches, see `_parts_for`
+  _lay: object = None                 # see `_layered_plan`
+  _lay_scale: tuple | None = None
 
   @classmethod
   def create(cls, vspace, pspace, dirichlet_mask=None,
@@ -1101,6 +1103,101 @@ class StokesDivGrad:
       w = exchange(w)
     return _ops.stokes_e_second(w, out, *args, scale)
 
+  # Layered D^T inside E (index-row kernels: 2D, and 3D outside the facet
+  # kernels' range).  The scatter of `sfem_stokes_grad_t` waits on the
+  # memory-side atomic unit as soon as a launch has enough elements (an
+  # ensemble of 8 Kolmogorov flows: 1.17 M requests in 72 us, 16 G/s).  The
+  # kernel needs no change to lose them: a second index row per element in
+  # which every (element, slot) writer of a shared node has a position of its
+  # OWN -- the first writer keeps the node, the others get positions behind
+  # the N nodes -- and no SHARED flag, so every slot takes the kernel's
+  # plain-store branch (nothing to clear either).  The sums are then formed by
+  # the class kernel that applies QQ^T to periodic images anyway
+  # (`sfem_exchange_classes`): a class is all positions of all images of a
+  # node.  `sfem_stokes_div` reads the first N positions of each component.
+  def _layered_plan(self):
+    """None, or (enc, n_ext, node_of_pos, members, offsets, num_classes)."""
+    if self._lay is None:
+      mesh = self.vspace.mesh
+      ok = (self.facet_parts is None and mesh.axis_name is None and
+            mesh.neighbor_plan is None and
+            mesh.elements.numel() <= (1 << 28))
+      self._lay = self._build_layered(mesh) if ok else False
+    return self._lay or None
+
+  def _build_layered(self, mesh):
+    dev = mesh.device
+    N = mesh.num_nodes
+    el = mesh.elements.to(torch.int64).reshape(-1)
+    order = torch.argsort(el, stable=True)
+    ids = el[order]
+    first = torch.ones_like(ids, dtype=torch.bool)
+    first[1:] = ids[1:] != ids[:-1]
+    extra = ~first
+    pos_sorted = torch.where(first, ids, N + torch.cumsum(extra, 0) - 1)
+    pos = torch.empty_like(el)
+    pos[order] = pos_sorted
+    n_ext = N + int(extra.sum())
+    if n_ext >= _lib_idx_mask():
+      return False
+    node_of_pos = torch.cat([torch.arange(N, device=dev), ids[extra]])
+    pos32 = pos.to(torch.int32)
+    dirichlet = self.enc.reshape(-1) < 0           # SFEM_IDX_DIRICHLET: bit 31
+    enc = torch.where(dirichlet, pos32 | torch.tensor(
+        -2 ** 31, dtype=torch.int32, device=dev), pos32).reshape(
+            self.enc.shape).contiguous()
+    # classes: positions of one node and of its periodic images
+    key = torch.arange(N, device=dev)
+    gi, ui = mesh.exchange_gather_indices, mesh.exchange_unique_indices
+    if gi is not None and gi.numel() and ui is not None:
+      g = gi.to(torch.int64)
+      u = torch.as_tensor(np.asarray(ui).astype(np.int64), device=dev)
+      keep = g >= 0
+      key[g[keep]] = N + u[keep]
+    pkey = key[node_of_pos]
+    korder = torch.argsort(pkey, stable=True)
+    _, counts = torch.unique_consecutive(pkey[korder], return_counts=True)
+    big = counts > 1
+    members = korder[torch.repeat_interleave(big, counts)]
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                         torch.cumsum(counts[big], 0)])
+    return (enc, n_ext, node_of_pos, members.to(torch.int32).contiguous(),
+            offsets.to(torch.int32).contiguous(), int(big.sum()))
+
+  def supports_layered_e(self) -> bool:
+    return self._layered_plan() is not None
+
+  def e_layered(self, p, scale=None, dot_with=None, dot_out=None):
+    """(Np,) -> (Np,):  D [ QQ^T ( scale * mask * D^T p ) ]  = `StokesSEM.E`
+    for a diagonal Q, the direct-stiffness sum of D^T without atomics (see
+    `_layered_plan`); periodic images included, one partition."""
+    enc, n_ext, node_of_pos, members, offsets, num_classes = \
+        self._layered_plan()
+    mesh = self.vspace.mesh
+    if tuple(p.shape) != (self.num_pressure_nodes,):
+      raise ValueError(f'expected ({self.num_pressure_nodes},) pressure, got '
+                       f'{tuple(p.shape)}')
+    from swirl_fem_amd.core import layout
+    p = p.to(self.vspace.dtype).contiguous()
+    w = layout.empty_component_major((n_ext, mesh.ndim), p.dtype, p.device)
+    if scale is not None:
+      if self._lay_scale is None or self._lay_scale[0] is not scale:
+        ext = scale.to(p.dtype).index_select(0, node_of_pos)
+        ext = (ext.contiguous() if ext.dim() == 1
+               else _like_layout(ext.expand_as(w), w))
+        self._lay_scale = (scale, ext)
+      scale = self._lay_scale[1]
+    P = mesh.gridpoints_1d.num_points
+    _ops.stokes_grad_t(p, w, enc, self.penc, self.parts, self.host, mesh.ndim,
+                       P, (0, 0), None, scale)
+    _ops.exchange_classes_(w, members, offsets, num_classes)
+    out = (torch.empty if self.penc is None else torch.zeros)(
+        self.num_pressure_nodes, dtype=p.dtype, device=p.device)
+    if dot_out is not None:
+      dot_with = dot_with.to(p.dtype).contiguous()
+    return _ops.stokes_div(w, out, self.enc, self.penc, self.parts, self.host,
+                           mesh.ndim, P, None, dot_with, dot_out)
+
   def div(self, u, scale=None, out=None, dot_with=None, dot_out=None):
     """(N, d) -> (Np,):  D (scale * u); `scale` is (N, d) or (N,).
     `dot_out`: SFEM_DOT_SLOTS doubles accumulating `dot_with . result`."""
@@ -1154,6 +1251,11 @@ class StokesDivGrad:
                               self._parts_for(out), self.host, mesh.ndim,
                               mesh.gridpoints_1d.num_points, self.zero_range,
                               self.shared_order, scale)
+
+
+def _lib_idx_mask():
+  from swirl_fem_amd import _lib
+  return _lib.SFEM_IDX_MASK
 
 
 def _diagonal_jacobian(coef):

@@ -765,6 +765,19 @@ class StokesSEM:
         return op.e_apply(
             p, scale=self._cache[key],
             exchange=partial(self.velocity.exchange, inplace=True))
+      # index-row kernels in 2D: D^T with a position per writer, the sums
+      # formed by the class kernel that serves the periodic images anyway --
+      # no atomics, nothing cleared, one launch less (`scripts/bench_ns.py`,
+      # ms per step atomic -> layered: Kolmogorov generator 10.1 -> 8.9,
+      # lid-driven cavity 35.6 -> 31.6, an ensemble of 8 flows 28.2 -> 22.5;
+      # 3D index rows gain nothing, `scripts/time_layered_e.py`: order 4 at
+      # 32^3 0.171 -> 0.169 ms per E, order 9 at 24^3 0.67 -> 0.73: opt-in)
+      lay = switches.get('SFEM_STOKES_LAYERED')
+      if (lay != '0' and not self.is_partitioned and
+          (lay == '1' or op.vspace.mesh.ndim == 2) and
+          op.supports_layered_e()):
+        return op.e_layered(p, scale=self._cache[key], dot_with=p,
+                            dot_out=dot_out)
       # Q is the same on every copy of a node, so it commutes with the
       # assembly and the exchange: applied inside D^T (whose scatter waits on
       # atomics anyway) it spares D one gather per node

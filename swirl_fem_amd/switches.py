@@ -77,6 +77,11 @@ SWITCHES = {
     'SFEM_SPLIT_E': ('0', 'navier_stokes/navier_stokes.py',
                      '1: pressure operator E in two fused halves '
                      '(`sfem_stokes_e_first/second`)'),
+    'SFEM_STOKES_LAYERED': ('auto', 'navier_stokes/navier_stokes.py',
+                            'pressure operator E on index-row kernels: D^T '
+                            'with one position per writer instead of atomics '
+                            '(`StokesDivGrad.e_layered`); auto = 2D meshes, '
+                            '1 = 3D index rows too, 0 = never'),
     'SFEM_FUSED_DOTS': ('1', 'navier_stokes/navier_stokes.py',
                         '0: the pressure CG computes p.Ep and r.Mr with '
                         'separate dot kernels'),

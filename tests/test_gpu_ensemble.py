@@ -257,3 +257,47 @@ def test_ensemble_kernels_against_a_host_recurrence(dtype):
   assert info2['member_status'][0] == 'maxiter'
   assert info2['member_status'][3] == 'converged'
   assert info2['status'] == 'maxiter'
+
+
+@pytest.mark.parametrize('case', ['periodic', 'walls', 'jittered3d'])
+def test_layered_pressure_operator_equals_the_atomic_one(case, monkeypatch):
+  """`StokesDivGrad.e_layered` (D^T with a position per writer, sums by the
+  class kernel, no atomics) against the default E, on the meshes that run the
+  index-row kernels: 2D periodic, 2D with Dirichlet walls, 3D at an order
+  outside the facet kernels."""
+  from swirl_fem_amd.common.premesh_commons import unit_cube_mesh
+  from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
+  if case == 'periodic':
+    sem = _sem(n=5, order=6)
+  elif case == 'walls':
+    sem = _sem(n=4, order=5, periodic=(),
+               bcs={'boundary': (BCType.DIRICHLET, 0.0)})
+  else:
+    sem = StokesSEM.create(unit_cube_mesh(3, ndim=3, periodic_dims=(0,)),
+                           {'boundary': (BCType.DIRICHLET, 0.0)}, order=4,
+                           device=DEV)
+  op = sem._divgrad()
+  assert op is not None and op.supports_layered_e()
+  g = torch.Generator(device=DEV).manual_seed(11)
+  Np = sem.pressure.pspace.mesh.num_nodes
+  p = torch.randn(Np, dtype=torch.float64, device=DEV, generator=g)
+  monkeypatch.setenv('SFEM_STOKES_LAYERED', '0')
+  want = sem.E(p, dt=1e-2, time_order=2)
+  monkeypatch.setenv('SFEM_STOKES_LAYERED', '1')
+  got = sem.E(p, dt=1e-2, time_order=2)
+  again = sem.E(p, dt=1e-2, time_order=2)
+  scale = float(want.abs().max())
+  assert float((got - want).abs().max()) <= 1e-12 * scale
+  assert torch.equal(got, again)          # fixed order of the sums
+  # with the fused p . E p
+  from swirl_fem_amd import _lib
+  parts = torch.zeros(_lib.SFEM_DOT_SLOTS, dtype=torch.float64, device=DEV)
+  sem.E(p, dt=1e-2, time_order=2, dot_out=parts)
+  assert abs(float(parts.sum()) - float(p @ want)) <= 1e-11 * abs(
+      float(p @ want))
+  # an ensemble of this mesh
+  ens = sem.ensemble(2)
+  pe = torch.cat([p, -0.5 * p])
+  ge = ens.unflatten(ens.E(pe, dt=1e-2, time_order=2))
+  assert float((ge[0] - want).abs().max()) <= 1e-12 * scale
+  assert float((ge[1] + 0.5 * want).abs().max()) <= 1e-12 * scale
