@@ -182,6 +182,37 @@ class _NullspaceProjection:
     return b1, float(total)
 
 
+class _MassPreconditioner:
+  """`z = (d_max / d) . QQ^T r` with d the assembled lumped velocity mass: an
+  opt-in preconditioner for the Helmholtz solve of the stepper (beyond the
+  reference, whose solve uses M = QQ^T alone, navier_stokes.py:436-438).
+
+  H = (beta / dt) B + mu A, and B is diagonal on GLL nodes: B^-1 H = beta / dt
+  (I + (dt mu / beta) B^-1 A) is close to a multiple of the identity whenever
+  the step is advection-dominated (dt mu / beta times the largest eigenvalue of
+  B^-1 A small: 3e-7 x O(1e5) for the Taylor-Green case of config 4), while H
+  itself inherits the spread of the GLL weights.  The factor d_max makes the
+  stopping rule at least as strict as the reference's: d_max / d >= 1, so
+  r . M r <= tol^2 b . b implies r . QQ^T r <= tol^2 b . b.  Commutes with
+  QQ^T (d is equal on the copies of a node), hence symmetric."""
+
+  capturable = True
+
+  def __init__(self, sem):
+    d = sem.velocity.exchange(sem.velocity_mass_diag)
+    top = sem._global_sum_max(d.max().reshape(1))
+    self.sem = sem
+    self.factor = (top / d) * sem.velocity.interior_mask
+    self._laid_out = {}
+
+  def __call__(self, r):
+    z = self.sem.velocity.exchange(r)
+    f = self._laid_out.get(z.stride())
+    if f is None:                  # (the solve's vectors: one layout per caller)
+      f = self._laid_out[z.stride()] = layout.like(self.factor, z).clone()
+    return f * z
+
+
 class _SolutionProjection:
   """Successive right-hand sides (Fischer, "Projection techniques for
   iterative solution of A x = b with successive right-hand sides", Comput.
@@ -618,6 +649,13 @@ class StokesSEM:
   def _reduce_fn(self):
     return self._global_sum if self.is_partitioned else None
 
+  def _global_sum_max(self, t):
+    """Maximum of a device tensor over the partitions."""
+    if self.is_partitioned:
+      from swirl_fem_amd.distributed import comm
+      comm.all_reduce_max_(t)
+    return t
+
   # ----------------------------------------------------------------- operators
   def B(self, u):
     """Apply the (diagonal) mass operator to a velocity field."""
@@ -795,9 +833,14 @@ class StokesSEM:
                       time_order: int, alpha: float = 0.05, u_boundary=None,
                       pressure_preconditioner=None,
                       project_out_nullspace=True, tol: float = 1e-8,
-                      atol: float = 0, pressure_projection: int | None = None
+                      atol: float = 0, pressure_projection: int | None = None,
+                      velocity_preconditioner=None
                       ) -> tuple[torch.Tensor, torch.Tensor, Any]:
     """Evolves the Stokes system by one fractional step (reference :350-458).
+
+    `velocity_preconditioner` (beyond the reference; None = the switch
+    SFEM_VELOCITY_PC, default 'exchange' = the reference's M = QQ^T): 'mass'
+    (`_MassPreconditioner`) or a callable r -> z for the Helmholtz solve.
 
     `pressure_projection` (beyond the reference; None = the switch
     SFEM_PRESSURE_PROJECTION, default 0 = off): number of earlier pressure
@@ -863,10 +906,24 @@ class StokesSEM:
     # solver vectors)
     limit = int(switches.get('SFEM_GRAPH_MAX_NUMEL'))
     small = lambda b: graph and b.numel() <= limit
-    u_star, info = _solve(diff, H_, f, M=self.velocity.exchange, tol=tol,
+    if velocity_preconditioner is None:
+      velocity_preconditioner = switches.get('SFEM_VELOCITY_PC')
+    vpc = velocity_preconditioner
+    if vpc == 'exchange':
+      M_v = self.velocity.exchange
+    elif vpc == 'mass':
+      if 'velocity_mass_pc' not in self._cache:
+        self._cache['velocity_mass_pc'] = _MassPreconditioner(self)
+      M_v = self._cache['velocity_mass_pc']
+    elif callable(vpc):
+      M_v = vpc
+    else:
+      raise ValueError(f'unknown velocity preconditioner {vpc!r}')
+    u_star, info = _solve(diff, H_, f, M=M_v, tol=tol,
                           atol=atol, graph=small(f),
                           reduce_fn=self._reduce_fn(), **ens,
-                          **(keep('H', beta_k / dt, float(mu))
+                          **(keep('H', beta_k / dt, float(mu),
+                                  vpc if isinstance(vpc, str) else id(vpc))
                              if small(f) else {}))
     if diff:
       u_star = self.velocity.interior_mask * u_star

@@ -101,6 +101,11 @@ SWITCHES = {
                          '(element-wise fast diagonalisation + piecewise-'
                          'constant coarse level, '
                          'navier_stokes/pressure_preconditioner.py)'),
+    'SFEM_VELOCITY_PC': ('exchange', 'navier_stokes/navier_stokes.py',
+                         "preconditioner of the stepper's Helmholtz solve: "
+                         "'exchange' (the reference's M = QQ^T) or 'mass' "
+                         '(inverse assembled lumped mass, scaled so that the '
+                         "reference's stopping rule still holds)"),
     'SFEM_PC_COARSE_ITERS': (None, 'navier_stokes/pressure_preconditioner.py',
                              'Chebyshev steps of the coarse solve inside the '
                              "'schwarz' preconditioner (default: from the "

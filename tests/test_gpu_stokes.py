@@ -1,5 +1,6 @@
 """GPU: `StokesSEM` (HIP path) vs the oracle and vs the analytic answers of
 the reference's navier_stokes_test.py:79-358."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -504,3 +505,36 @@ def test_schwarz_pressure_preconditioner():
   ia = sum(b for _, b in da['cg_iterations'])
   ib = sum(b for _, b in db['cg_iterations'])
   assert ib <= ia, (da['cg_iterations'], db['cg_iterations'])
+
+
+def test_mass_preconditioned_velocity_solve():
+  """Opt-in `velocity_preconditioner='mass'` (beyond the reference's M = QQ^T
+  for the stepper's Helmholtz solve): same step to the solver tolerance, a
+  fraction of the iterations, and a stopping rule at least as strict as the
+  reference's."""
+  from swirl_fem_amd.examples.navier_stokes_driver import taylor_green
+  from swirl_fem_amd.examples.navier_stokes_driver import navier_stokes_step
+  from swirl_fem_amd.navier_stokes import navier_stokes as ns
+  kw = dict(n=4, order=6, reynolds=400.0, dt=2e-3, steps=2, time_order=2,
+            device=DEV, tol=1e-10)
+  sem, u0, p0, d0 = taylor_green(**kw)
+  os.environ['SFEM_VELOCITY_PC'] = 'mass'
+  try:
+    sem1, u1, p1, d1 = taylor_green(**kw)
+  finally:
+    del os.environ['SFEM_VELOCITY_PC']
+  assert float((u1 - u0).abs().max()) <= 1e-8 * float(u0.abs().max())
+  assert float((p1 - p0).abs().max()) <= 1e-6 * max(1.0, float(p0.abs().max()))
+  it0 = [v for v, _ in d0['cg_iterations']]
+  it1 = [v for v, _ in d1['cg_iterations']]
+  assert all(b * 3 <= a for a, b in zip(it0, it1)), (it0, it1)
+  # M = (d_max / d) QQ^T: symmetric, and r . M r >= r . QQ^T r
+  M = ns._MassPreconditioner(sem)
+  g = torch.Generator(device=DEV).manual_seed(4)
+  N = sem.velocity.mesh.num_nodes
+  a = torch.randn(N, 3, dtype=torch.float64, device=DEV, generator=g)
+  b = torch.randn(N, 3, dtype=torch.float64, device=DEV, generator=g)
+  lhs, rhs = float((a * M(b)).sum()), float((b * M(a)).sum())
+  assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), 1.0)
+  assert float((a * M(a)).sum()) >= float(
+      (a * sem.velocity.exchange(a)).sum()) * (1 - 1e-12)
