@@ -29,7 +29,10 @@ tolerance, the default stays the reference's:
   int_e d(phi_n)/dx_c (sparse, 27 entries per row on a structured mesh) and
   applied through a fixed Chebyshev polynomial of the Jacobi-scaled E_0
   (`sfem_ell_chebyshev`: linear and symmetric, which a truncated inner CG is
-  not; spectrum bounds by Lanczos at setup);
+  not; spectrum bounds by Lanczos at setup); as a dense pseudo-inverse up to
+  4096 elements; and on a uniform, fully periodic box -- where E_0 is a
+  circulant stencil, verified against E_0 itself at setup -- exactly, by two
+  FFTs (`_circulant_coarse`);
 * P: the reference's nullspace projection.
 """
 
@@ -143,11 +146,11 @@ class SchwarzPressurePreconditioner:
     ident = torch.arange(self.pel.numel(), device=dev).reshape(self.pel.shape)
     self.pel_arg = None if torch.equal(self.pel, ident) else self.pel.contiguous()
     # --- coarse level
+    self.coarse_solver = coarse_solver
     self._build_coarse(q, dtype, dev)
     # steps for a residual reduction of ~ 1e-2 on [lmin, lmax]:
     # sqrt(kappa) ln(2 / eps) / 2
     lmin, lmax = self.coarse_bounds
-    self.coarse_solver = coarse_solver
     self.coarse_iterations = (int(coarse_iterations) if coarse_iterations
                               else max(8, int(np.ceil(
                                   np.sqrt(lmax / lmin) * np.log(200.0) / 2))))
@@ -216,6 +219,7 @@ class SchwarzPressurePreconditioner:
     # small coarse problems (a few thousand elements: launch-bound steps): the
     # pseudo-inverse as a dense matrix, one matrix-vector product per apply
     self.E0_pinv = None
+    self.E0_fft = None
     if E <= DENSE_COARSE_MAX:
       dense = torch.as_tensor(E0.toarray(), dtype=torch.float64, device=dev)
       w, V = torch.linalg.eigh(dense)
@@ -225,6 +229,15 @@ class SchwarzPressurePreconditioner:
       self.E0_pinv = ((V * winv[None, :]) @ V.t()).to(dtype).contiguous()
       self.coarse_bounds = (1.0, 2.0)          # (not used)
       return
+    # a uniform, fully periodic box: E_0 is a (block-)circulant 27-point
+    # stencil, which the discrete Fourier transform diagonalises -- the exact
+    # pseudo-inverse for two small FFTs
+    self.E0_fft = None
+    if self.members == 1 and self.coarse_solver == 'chebyshev':
+      self.E0_fft = self._circulant_coarse(E0, dtype, dev)
+      if self.E0_fft is not None:
+        self.coarse_bounds = (1.0, 2.0)        # (not used)
+        return
     # spectrum of D^-1 E_0 on the complement of the constants: Lanczos (host,
     # SciPy, setup only) for the two ends; the Chebyshev polynomial is built
     # for [lmin, lmax] and stays positive definite as long as lmax is a bound
@@ -245,6 +258,51 @@ class SchwarzPressurePreconditioner:
       lmin = float(got[-1]) if len(got) >= k else lmax / (4.0 * E ** (2.0 / d))
     self.coarse_bounds = (0.8 * max(lmin, 1e-12 * lmax), 1.05 * lmax)
 
+  def _circulant_coarse(self, E0, dtype, dev):
+    """(perm, 1 / symbol) if the elements form a full tensor grid on which E_0
+    is translation-invariant with periodic wrap-around (checked against E_0
+    itself on a random vector), else None."""
+    vmesh = self.sem.velocity.mesh
+    d = self.d
+    xc = vmesh.element_coords().mean(dim=1).cpu().numpy()        # (E, d)
+    E = xc.shape[0]
+    span = np.ptp(xc, axis=0).max() or 1.0
+    idx, shape = [], []
+    for a in range(d):
+      vals = np.unique(np.round(xc[:, a] / span, 9))
+      shape.append(len(vals))
+      idx.append(np.searchsorted(vals, np.round(xc[:, a] / span, 9)))
+    if int(np.prod(shape)) != E or min(shape) < 3:
+      return None
+    lin = np.ravel_multi_index(tuple(idx), tuple(shape))
+    if len(np.unique(lin)) != E:
+      return None
+    perm = np.empty(E, dtype=np.int64)       # grid position -> element
+    perm[lin] = np.arange(E)
+    row = E0.getrow(int(perm[0]))
+    stencil = np.zeros(shape)
+    off = np.unravel_index(lin[row.indices], tuple(shape))
+    np.add.at(stencil, off, row.data)
+    symbol = np.fft.rfftn(stencil)
+    if np.abs(symbol.imag).max() > 1e-9 * np.abs(symbol.real).max():
+      return None
+    symbol = symbol.real
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal(E)
+    want = E0 @ v
+    got = np.empty(E)
+    axes = tuple(range(d))
+    got[perm] = np.fft.irfftn(symbol * np.fft.rfftn(v[perm].reshape(shape)),
+                              s=shape, axes=axes).reshape(-1)
+    if np.abs(got - want).max() > 1e-9 * np.abs(want).max():
+      return None
+    top = np.abs(symbol).max()
+    inv = np.where(np.abs(symbol) > 1e-10 * top,
+                   1.0 / np.where(symbol == 0, 1.0, symbol), 0.0)
+    ident = bool((perm == np.arange(E)).all())
+    return (None if ident else torch.as_tensor(perm, device=dev),
+            torch.as_tensor(inv, dtype=dtype, device=dev), tuple(shape))
+
   def coarse_matvec(self, x):
     return (self.E0_vals * x[self.E0_cols]).sum(dim=1)
 
@@ -253,6 +311,15 @@ class SchwarzPressurePreconditioner:
     polynomial of the Jacobi-scaled coarse matrix (`sfem_ell_chebyshev`: one
     small launch per step, no inner products, exactly linear and symmetric);
     `coarse_solver = 'cg'` keeps the truncated CG of the first version."""
+    if self.E0_fft is not None:
+      perm, inv, shape = self.E0_fft
+      v = (b if perm is None else b[perm]).reshape(shape)
+      x = torch.fft.irfftn(torch.fft.rfftn(v) * inv, s=shape).reshape(-1)
+      if perm is None:
+        return x
+      out = torch.empty_like(x)
+      out[perm] = x
+      return out
     if self.E0_pinv is not None and self.coarse_solver == 'chebyshev':
       if self.members > 1:        # (the pseudo-inverse is symmetric)
         return (b.view(self.members, -1) @ self.E0_pinv).reshape(-1)

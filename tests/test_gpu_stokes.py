@@ -538,3 +538,44 @@ def test_mass_preconditioned_velocity_solve():
   assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), 1.0)
   assert float((a * M(a)).sum()) >= float(
       (a * sem.velocity.exchange(a)).sum()) * (1 - 1e-12)
+
+
+def test_schwarz_coarse_solve_by_fft_on_a_periodic_box(monkeypatch):
+  """On a uniform, fully periodic box the coarse operator R_0 E R_0^T is a
+  circulant stencil: the preconditioner applies its exact pseudo-inverse by two
+  FFTs (found by checking E_0 itself, not assumed); a mesh with walls keeps
+  the Chebyshev solve."""
+  from swirl_fem_amd.common.premesh_commons import box_mesh, unit_cube_mesh
+  from swirl_fem_amd.navier_stokes import pressure_preconditioner as pc
+  from swirl_fem_amd.navier_stokes.navier_stokes import BCType, StokesSEM
+  monkeypatch.setattr(pc, 'DENSE_COARSE_MAX', 0)
+  g = torch.Generator(device=DEV).manual_seed(21)
+  for pm in (box_mesh((4, 5, 3), (0.0,) * 3, (1.0, 2.0, 0.5),
+                      periodic_dims=(0, 1, 2)),
+             unit_cube_mesh(6, ndim=2, periodic_dims=(0, 1))):
+    sem = StokesSEM.create(pm, {}, order=4, device=DEV)
+    M = pc.SchwarzPressurePreconditioner(sem, 1e-2, 2)
+    assert M.E0_fft is not None and M.E0_pinv is None
+    E = M.pel.shape[0]
+    dense = torch.zeros(E, E, dtype=torch.float64, device=DEV)
+    dense.scatter_add_(1, M.E0_cols, M.E0_vals.double())
+    pinv = torch.linalg.pinv(dense, hermitian=True, rtol=1e-10)
+    b = torch.randn(E, dtype=torch.float64, device=DEV, generator=g)
+    want = pinv @ b
+    got = M._coarse_solve(b)
+    assert float((got - want).abs().max()) <= 1e-9 * float(want.abs().max())
+    # ... and the whole preconditioner stays symmetric on zero-sum vectors
+    n = sem.pressure.pspace.mesh.num_nodes
+    a = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    c = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    a, c = a - a.mean(), c - c.mean()
+    lhs, rhs = float(torch.dot(M(a), c)), float(torch.dot(a, M(c)))
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs))
+  walls = StokesSEM.create(unit_cube_mesh(6, ndim=2),
+                           {'boundary': (BCType.DIRICHLET, 0.0)}, order=4,
+                           device=DEV)
+  assert pc.SchwarzPressurePreconditioner(walls, 1e-2, 2).E0_fft is None
+  half = StokesSEM.create(unit_cube_mesh(6, ndim=2, periodic_dims=(0,)),
+                          {'boundary': (BCType.DIRICHLET, 0.0)}, order=4,
+                          device=DEV)
+  assert pc.SchwarzPressurePreconditioner(half, 1e-2, 2).E0_fft is None
