@@ -26,7 +26,7 @@ if [ -n "$PATCH" ]; then
 fi
 cd "$work"
 objs=""
-for o in sfem_core sfem_basis sfem_fdm sfem_cg_ensemble sfem_helmholtz sfem_helmholtz_f64_3d sfem_helmholtz_f64_2d sfem_helmholtz_f32_3d sfem_helmholtz_f32_2d sfem_helmholtz_cluster_f64 sfem_helmholtz_cluster_f32 sfem_helmholtz_mfma sfem_helmholtz_facet_f64 sfem_helmholtz_facet_f32 sfem_helmholtz_facet_f64_hi sfem_helmholtz_facet_f32_hi sfem_stokes_facet_f64 sfem_stokes_facet_f32 sfem_stokes sfem_stokes_f64_3d sfem_stokes_f64_2d sfem_stokes_f32_3d sfem_stokes_f32_2d; do
+for o in sfem_core sfem_basis sfem_fdm sfem_cg_ensemble sfem_interp_f64 sfem_interp_f32 sfem_helmholtz sfem_helmholtz_f64_3d sfem_helmholtz_f64_2d sfem_helmholtz_f32_3d sfem_helmholtz_f32_2d sfem_helmholtz_cluster_f64 sfem_helmholtz_cluster_f32 sfem_helmholtz_mfma sfem_helmholtz_facet_f64 sfem_helmholtz_facet_f32 sfem_helmholtz_facet_f64_hi sfem_helmholtz_facet_f32_hi sfem_stokes_facet_f64 sfem_stokes_facet_f32 sfem_stokes sfem_stokes_f64_3d sfem_stokes_f64_2d sfem_stokes_f32_3d sfem_stokes_f32_2d; do
   if [[ " $units " == *" $o "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-unused-function -Wno-array-bounds -I../../include -I. "$@" -c $o.hip -o /tmp/${o}_$name.o
     objs="$objs /tmp/${o}_$name.o"

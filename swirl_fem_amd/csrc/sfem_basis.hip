@@ -8,6 +8,8 @@
 // core/interpolation.py:260-263).  The tuned collocated Helmholtz/mass/
 // stiffness operator lives in sfem_helmholtz.hip.
 #include "sfem_common.h"
+#include "sfem_interp.h"
+#include <cstdlib>
 
 namespace sfem {
 
@@ -292,6 +294,12 @@ int launch_basis_eval_t(const BasisTArgs<T>& a, hipStream_t stream) {
   return SFEM_OK;
 }
 
+// SFEM_INTERP=0: the values-only cases run the generic kernels too (A/B)
+static bool interp_enabled() {
+  const char* v = std::getenv("SFEM_INTERP");
+  return !(v && v[0] == '0');
+}
+
 static int check_shape(const char* who, int64_t E, int ndim, int P, int q,
                        int ncomp) {
   SFEM_REQUIRE(E >= 0, "%s: negative element count", who);
@@ -319,6 +327,24 @@ int sfem_basis_eval(const void* u_local, const void* interp1,
   SFEM_REQUIRE(!collocated || P == q, "sfem_basis_eval: collocated needs P==q");
   if (num_elements == 0 || (!val && !grad)) return SFEM_OK;
   SFEM_REQUIRE(u_local && interp1 && grad1, "sfem_basis_eval: null pointer");
+  if (val && !grad && !collocated && interp_enabled()) {
+    // values only: the compile-time-sized interpolation (sfem_interp.h), same
+    // bits as the generic kernel below
+    const int rc =
+        dtype == SFEM_F64
+            ? launch_tensor_interp_f64(ndim, P, q, u_local, interp1, nullptr,
+                                       val, num_elements, ncomp, false,
+                                       as_stream(stream))
+            : (dtype == SFEM_F32
+                   ? launch_tensor_interp_f32(ndim, P, q, u_local, interp1,
+                                              nullptr, val, num_elements, ncomp,
+                                              false, as_stream(stream))
+                   : SFEM_EUNSUPPORTED);
+    if (rc == SFEM_OK) {
+      SFEM_LAUNCH_CHECK();
+      return SFEM_OK;
+    }
+  }
   if (dtype == SFEM_F64) {
     BasisArgs<double> a{(const double*)u_local, (const double*)interp1,
                         (const double*)grad1, (const double*)invjac,
@@ -349,6 +375,23 @@ int sfem_basis_eval_t(const void* c0, const void* c1, const void* interp1,
   SFEM_REQUIRE(interp1 && grad1 && wdet && out,
                "sfem_basis_eval_t: null pointer");
   SFEM_REQUIRE(!c1 || invjac, "sfem_basis_eval_t: c1 needs invjac");
+  if (c0 && !c1 && !collocated && interp_enabled()) {
+    // out = (I^T (x) .. (x) I^T)(wdet .* c0), compile-time sizes
+    const int rc =
+        dtype == SFEM_F64
+            ? launch_tensor_interp_f64(ndim, q, P, c0, interp1, wdet, out,
+                                       num_elements, ncomp, true,
+                                       as_stream(stream))
+            : (dtype == SFEM_F32
+                   ? launch_tensor_interp_f32(ndim, q, P, c0, interp1, wdet, out,
+                                              num_elements, ncomp, true,
+                                              as_stream(stream))
+                   : SFEM_EUNSUPPORTED);
+    if (rc == SFEM_OK) {
+      SFEM_LAUNCH_CHECK();
+      return SFEM_OK;
+    }
+  }
   if (dtype == SFEM_F64) {
     BasisTArgs<double> a{(const double*)c0, (const double*)c1,
                          (const double*)interp1, (const double*)grad1,

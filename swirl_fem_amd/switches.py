@@ -63,6 +63,10 @@ SWITCHES = {
                             'order instead of node order'),
     'SFEM_CLUSTER': ('0', 'core/operators.py',
                      "1: assembly='auto' means cluster assembly (slower)"),
+    'SFEM_INTERP': ('1', 'the library (getenv per launch)',
+                    '0: values-only sfem_basis_eval / sfem_basis_eval_t run '
+                    'the generic kernels instead of the compile-time-sized '
+                    'interpolation (csrc/sfem_interp.h)'),
     'SFEM_MFMA': ('0', '_ops.py and the library (getenv per launch)',
                   '1: p = 11 fp32 index-row elements run the matrix-core '
                   'kernel (slower: 1.25 vs 1.0 ms)'),
