@@ -83,6 +83,12 @@ def all_gather(t: torch.Tensor) -> list:
   if _TRANSPORT is not None:
     return _TRANSPORT.all_gather(t)
   if dist.is_available() and dist.is_initialized() and get_world_size() > 1:
+    if t.is_cuda and dist.get_backend() == 'gloo':
+      # gloo gathers host memory only (single-GPU rehearsals of the ranks)
+      host = t.cpu()
+      every = [torch.zeros_like(host) for _ in range(get_world_size())]
+      dist.all_gather(every, host)
+      return [e.to(t.device) for e in every]
     every = [torch.zeros_like(t) for _ in range(get_world_size())]
     dist.all_gather(every, t)
     return every

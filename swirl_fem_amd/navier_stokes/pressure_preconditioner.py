@@ -83,9 +83,11 @@ class SchwarzPressurePreconditioner:
     d = self.d = vmesh.ndim
     P = self.P = vmesh.gridpoints_1d.num_points
     Pp = self.Pp = pmesh.gridpoints_1d.num_points
-    if sem.is_partitioned:
-      raise NotImplementedError('Schwarz pressure preconditioner on a '
-                                'partitioned mesh')
+    # partitions: the local part is element-wise (no communication); the
+    # coarse level is solved redundantly on every rank after one all-gather of
+    # the element sums -- for uniform periodic boxes cut into blocks
+    # (BASELINE config 4), where it is a circulant stencil (`_circulant_blocks`)
+    self.partitioned = sem.is_partitioned
     dev, dtype = vmesh.device, vmesh.node_coords.dtype
     E = vmesh.num_elements
     self.pel = pmesh.elements.to(torch.int64)       # (E, Pp^d)
@@ -220,13 +222,24 @@ class SchwarzPressurePreconditioner:
     # pseudo-inverse as a dense matrix, one matrix-vector product per apply
     self.E0_pinv = None
     self.E0_fft = None
-    if E <= DENSE_COARSE_MAX:
+    self.E0_blocks = None
+    if E <= DENSE_COARSE_MAX and not self.partitioned:
       dense = torch.as_tensor(E0.toarray(), dtype=torch.float64, device=dev)
       w, V = torch.linalg.eigh(dense)
       keep = w > 1e-10 * w.abs().max()
       winv = torch.where(keep, 1.0 / torch.where(keep, w, torch.ones_like(w)),
                          torch.zeros_like(w))
       self.E0_pinv = ((V * winv[None, :]) @ V.t()).to(dtype).contiguous()
+      self.coarse_bounds = (1.0, 2.0)          # (not used)
+      return
+    if self.partitioned:
+      self.E0_fft = None
+      self.E0_blocks = self._circulant_blocks(E0, dtype, dev)
+      if self.E0_blocks is None:
+        raise NotImplementedError(
+            'Schwarz pressure preconditioner on a partitioned mesh needs a '
+            'uniform, fully periodic box cut into blocks of at least 3 '
+            'elements per direction (coarse solve by FFT)')
       self.coarse_bounds = (1.0, 2.0)          # (not used)
       return
     # a uniform, fully periodic box: E_0 is a (block-)circulant 27-point
@@ -303,6 +316,72 @@ class SchwarzPressurePreconditioner:
     return (None if ident else torch.as_tensor(perm, device=dev),
             torch.as_tensor(inv, dtype=dtype, device=dev), tuple(shape))
 
+  def _circulant_blocks(self, E0, dtype, dev):
+    """The circulant coarse operator of a periodic box held as blocks by the
+    ranks: (own grid positions, everyone's grid positions, 1 / symbol, global
+    shape), or None.  `E0` holds this rank's rows with the columns of its own
+    elements; the rows of elements away from the block's faces are complete
+    and give the stencil; the symbol is checked against them."""
+    from swirl_fem_amd.distributed import comm
+    vmesh = self.sem.velocity.mesh
+    d = self.d
+    xc = vmesh.element_coords().mean(dim=1)                     # (E, d)
+    E = xc.shape[0]
+    hi = comm.all_reduce_max_(xc.max(dim=0).values.clone())
+    lo = -comm.all_reduce_max_((-xc).max(dim=0).values.clone())
+    xc, lo, hi = xc.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy()
+    shape, gidx = [], []
+    for a in range(d):
+      vals = np.unique(np.round(xc[:, a] / max(hi[a] - lo[a], 1e-300), 9))
+      if len(vals) < 2:
+        return None
+      h = (vals[1] - vals[0]) * (hi[a] - lo[a])
+      n = int(round((hi[a] - lo[a]) / h)) + 1
+      k = np.round((xc[:, a] - lo[a]) / h).astype(np.int64)
+      if np.abs((xc[:, a] - lo[a]) / h - k).max() > 1e-6 or n < 3:
+        return None
+      shape.append(n)
+      gidx.append(k)
+    glin = np.ravel_multi_index(tuple(gidx), tuple(shape))
+    if len(np.unique(glin)) != E:
+      return None
+    nnz = np.diff(E0.indptr)
+    full = 3 ** d
+    if nnz.max() != full:
+      return None
+    row = E0.getrow(int(np.argmax(nnz)))
+    i0 = int(np.argmax(nnz))
+    stencil = np.zeros(shape)
+    off = tuple((gidx[a][row.indices] - gidx[a][i0]) % shape[a]
+                for a in range(d))
+    np.add.at(stencil, off, row.data)
+    axes = tuple(range(d))
+    symbol = np.fft.rfftn(stencil, axes=axes)
+    if np.abs(symbol.imag).max() > 1e-9 * np.abs(symbol.real).max():
+      return None
+    symbol = symbol.real
+    # check on the complete rows: E_0 v against the FFT product for a v that
+    # is the same on every rank
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal(shape)
+    Y = np.fft.irfftn(symbol * np.fft.rfftn(V, axes=axes), s=shape, axes=axes)
+    rows = np.nonzero(nnz == full)[0]
+    want = (E0[rows] @ V.reshape(-1)[glin])
+    got = Y.reshape(-1)[glin[rows]]
+    ok = np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+    flag = torch.tensor([0.0 if ok else 1.0], device=dev)
+    if float(comm.all_reduce_max_(flag)) != 0.0:
+      return None
+    top = np.abs(symbol).max()
+    inv = np.where(np.abs(symbol) > 1e-10 * top,
+                   1.0 / np.where(symbol == 0, 1.0, symbol), 0.0)
+    mine = torch.as_tensor(glin, device=dev)
+    everyone = torch.cat(comm.all_gather(mine))
+    if everyone.numel() != int(np.prod(shape)):
+      return None
+    return (mine, everyone, torch.as_tensor(inv, dtype=dtype, device=dev),
+            tuple(shape))
+
   def coarse_matvec(self, x):
     return (self.E0_vals * x[self.E0_cols]).sum(dim=1)
 
@@ -311,6 +390,13 @@ class SchwarzPressurePreconditioner:
     polynomial of the Jacobi-scaled coarse matrix (`sfem_ell_chebyshev`: one
     small launch per step, no inner products, exactly linear and symmetric);
     `coarse_solver = 'cg'` keeps the truncated CG of the first version."""
+    if self.E0_blocks is not None:
+      from swirl_fem_amd.distributed import comm
+      mine, everyone, inv, shape = self.E0_blocks
+      G = torch.empty(everyone.numel(), dtype=b.dtype, device=b.device)
+      G[everyone] = torch.cat(comm.all_gather(b.contiguous()))
+      X = torch.fft.irfftn(torch.fft.rfftn(G.reshape(shape)) * inv, s=shape)
+      return X.reshape(-1)[mine]
     if self.E0_fft is not None:
       perm, inv, shape = self.E0_fft
       v = (b if perm is None else b[perm]).reshape(shape)
