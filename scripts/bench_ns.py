@@ -50,7 +50,8 @@ def kolmogorov(steps=60, warm=10):
       'velocity_dofs': 2 * sem.velocity.mesh.num_nodes, 'pressure_dofs': sem.pressure.pspace.mesh.num_nodes,
       'max_divergence': float(sem.D(us[-1]).abs().max()), 'max_velocity': float(us[-1].abs().max()),
       'dtype': 'f64', 'hip_graphs': os.environ.get('SFEM_GRAPHS', '1') != '0',
-      'peak_memory_gb': torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+      'peak_memory_gb': torch.cuda.max_memory_allocated() / 1e9,
+      'switches': switches.active()}), flush=True)
 
 
 for key in (sys.argv[1:] or ['cavity', 'tgv16']):
