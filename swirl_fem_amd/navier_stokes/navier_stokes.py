@@ -230,41 +230,51 @@ class _SolutionProjection:
   application of E and four passes over the basis -- against hundreds of
   iterations."""
 
-  def __init__(self, size: int, dot):
-    self.size, self.dot = int(size), dot
-    self.X = self.W = None        # (l, Np) each
+  def __init__(self, size: int, reduce=None, members: int = 1):
+    """`reduce`: in-place sum over the partitions (or None); `members`: an
+    ensemble keeps one basis per member (the vectors are `(B Np,)`, member m
+    in [m Np, (m + 1) Np): every coefficient below has a member axis)."""
+    self.size, self.reduce, self.members = int(size), reduce, int(members)
+    self.X = self.W = None        # (l, B, Np) each
     self.count = 0
+
+  def _dots(self, X, v):
+    """(l, B, Np) x (B, Np) -> (l, B), over all ranks."""
+    out = torch.einsum('lbn,bn->lb', X, v)
+    return out if self.reduce is None else self.reduce(out)
 
   def guess(self, b):
     if self.count == 0:
       return None
     X = self.X[:self.count]
-    alpha = self.dot(X, b)                       # (l,)
-    return torch.mv(X.t(), alpha)
+    alpha = self._dots(X, b.reshape(self.members, -1))          # (l, B)
+    return torch.einsum('lb,lbn->bn', alpha, X).reshape(b.shape)
 
   def update(self, x, x0, apply_e):
+    B = self.members
     d = x if x0 is None else x - x0
     if self.X is None:
-      self.X = torch.zeros((self.size,) + tuple(x.shape), dtype=x.dtype,
+      self.X = torch.zeros((self.size, B, x.numel() // B), dtype=x.dtype,
                            device=x.device)
       self.W = torch.zeros_like(self.X)
     if self.count == self.size:
       # full: start again from the newest solution (it carries what the old
       # basis knew about the current time level)
       self.count, d = 0, x
-    w = apply_e(d)
+    w = apply_e(d).reshape(B, -1)
+    d = d.reshape(B, -1)
     if self.count:
       X, W = self.X[:self.count], self.W[:self.count]
-      beta = self.dot(X, w)
-      d = d - torch.mv(X.t(), beta)
-      w = w - torch.mv(W.t(), beta)
-    nrm2 = self.dot(d[None], w)[0]
+      beta = self._dots(X, w)
+      d = d - torch.einsum('lb,lbn->bn', beta, X)
+      w = w - torch.einsum('lb,lbn->bn', beta, W)
+    nrm2 = self._dots(d[None], w)[0]                            # (B,)
     ok = nrm2 > 0
     scale = torch.where(ok, torch.rsqrt(torch.where(ok, nrm2,
                                                     torch.ones_like(nrm2))),
                         torch.zeros_like(nrm2))
-    self.X[self.count] = d * scale
-    self.W[self.count] = w * scale
+    self.X[self.count] = d * scale[:, None]
+    self.W[self.count] = w * scale[:, None]
     self.count += 1
 
 
@@ -943,12 +953,8 @@ class StokesSEM:
              int(pressure_projection))
       hist = self._cache.get(key)
       if hist is None:
-        reduce = self._reduce_fn()
-        def dots(X, v):           # (l, Np) x (Np,) -> (l,), over all ranks
-          out = torch.mv(X, v)
-          return out if reduce is None else reduce(out)
-        hist = self._cache[key] = _SolutionProjection(pressure_projection,
-                                                      dots)
+        hist = self._cache[key] = _SolutionProjection(
+            pressure_projection, self._reduce_fn(), self.members)
       dp0 = hist.guess(rhs)
     dp, info = _solve(diff, E_, rhs, x0=dp0,
                       M=pressure_preconditioner, tol=tol, atol=atol,
