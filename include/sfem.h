@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SFEM_ABI_VERSION 6
+#define SFEM_ABI_VERSION 7
 
 enum { SFEM_F32 = 0, SFEM_F64 = 1 };
 enum {
@@ -672,6 +672,24 @@ int sfem_fdm_solve(const void* r, void* z, const int64_t* pel, const void* S,
                    const int32_t* cases, const void* inv_eigenvalues,
                    int64_t num_elements, int ndim, int Pp, int dtype,
                    sfem_stream_t stream);
+/* The same solve that also hands back, per element, elem_sum[e] = sum of r
+ * over the element (the restriction R_0 r of the coarse level) and, when
+ * `weighted_sum` is given, weighted_sum[e] = sum_i weights[node] z[node] (the
+ * element's share of the mean projection that closes the preconditioner):
+ * two vector passes less per application.                                    */
+int sfem_fdm_solve_sums(const void* r, void* z, const int64_t* pel,
+                        const void* S, const int32_t* cases,
+                        const void* inv_eigenvalues, const void* weights,
+                        void* elem_sum, void* weighted_sum,
+                        int64_t num_elements, int ndim, int Pp, int dtype,
+                        sfem_stream_t stream);
+/* z[e n + i] += yc[e] - shift[e / elems_per_member] (element e owns the nodes
+ * [e n, (e + 1) n)): coarse correction and mean removal in one pass; `shift`
+ * is a device array (one value per ensemble member, 1 without ensembles).    */
+int sfem_add_element_constants(void* z, const void* yc, const void* shift,
+                               int64_t num_elements, int n,
+                               int64_t elems_per_member, int dtype,
+                               sfem_stream_t stream);
 /* x = q(D^-1 A) D^-1 b: `steps` steps of the Chebyshev iteration for the
  * interval [lmin, lmax] of the Jacobi-scaled sparse matrix A, a FIXED
  * polynomial (no inner products; linear, symmetric positive definite whenever

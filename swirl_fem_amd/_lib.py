@@ -15,7 +15,7 @@ from swirl_fem_amd import switches
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SFEM_LIB: another build of the same library (kernel A/B experiments)
 LIB_PATH = switches.get('SFEM_LIB') or os.path.join(_HERE, 'libsfem_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SFEM_F32, SFEM_F64 = 0, 1
 SFEM_CG_NSCALARS_NAMED = 16
@@ -132,6 +132,10 @@ SIGNATURES = {
     'sfem_kernarg_selftest': [c_ptr, c_ptr],
     'sfem_fdm_solve': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                        c_i32, c_i32, c_ptr],
+    'sfem_fdm_solve_sums': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                            c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr],
+    'sfem_add_element_constants': [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64,
+                                   c_i32, c_ptr],
     'sfem_ell_chebyshev': [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                            c_i32, c_i32, c_dbl, c_dbl, c_i32, c_ptr],
     'sfem_ens_dot': [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_i32, c_ptr],

@@ -734,6 +734,35 @@ def fdm_solve(r, pel, S, cases, inv_ev, ndim, Pp):
   return z
 
 
+def fdm_solve_sums(r, pel, S, cases, inv_ev, weights, ndim, Pp):
+  """`fdm_solve` that also returns the element sums of r and the elements'
+  shares of weights . z (`sfem_fdm_solve_sums`)."""
+  dev = _dev(r, pel, S, cases, inv_ev, weights)
+  E = cases.shape[1]
+  z = torch.empty_like(r)
+  elem_sum = torch.empty(E, dtype=r.dtype, device=r.device)
+  weighted = torch.empty(E, dtype=r.dtype, device=r.device)
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_fdm_solve_sums(
+        _ptr(r), _ptr(z), _ptr(pel), _ptr(S), _ptr(cases), _ptr(inv_ev),
+        _ptr(weights), _ptr(elem_sum), _ptr(weighted), E, int(ndim), int(Pp),
+        _dtype_code(r), _stream(dev)), 'sfem_fdm_solve_sums')
+  return z, elem_sum, weighted
+
+
+def add_element_constants_(z, yc, shift, n, elems_per_member):
+  """In place: z[e n + i] += yc[e] - shift[e // elems_per_member]."""
+  dev = _dev(z, yc, shift)
+  if not z.is_contiguous() or z.numel() != yc.numel() * n:
+    raise ValueError('add_element_constants_: z is (E n,) contiguous')
+  with torch.cuda.device(dev):
+    _lib.check(_lib.load().sfem_add_element_constants(
+        _ptr(z), _ptr(yc.contiguous()), _ptr(shift.contiguous()), yc.numel(),
+        int(n), int(elems_per_member), _dtype_code(z), _stream(dev)),
+        'sfem_add_element_constants')
+  return z
+
+
 def ell_chebyshev(cols, vals, dinv, b, steps, lmin, lmax, work=None):
   """x = Chebyshev polynomial of the Jacobi-scaled ELL matrix applied to b
   (`sfem_ell_chebyshev`); cols / vals (width, n) int32 / real."""

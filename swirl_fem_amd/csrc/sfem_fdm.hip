@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(64)
 fdm_solve_kernel(const T* __restrict__ r, T* __restrict__ z,
                  const int64_t* __restrict__ pel, const T* __restrict__ S,
                  const int32_t* __restrict__ cases, const T* __restrict__ w,
-                 int64_t num_elements) {
+                 int64_t num_elements, const T* __restrict__ weights,
+                 T* __restrict__ elem_sum, T* __restrict__ weighted_sum) {
   constexpr int N = D == 3 ? PP * PP * PP : (D == 2 ? PP * PP : PP);
   __shared__ T buf[2][N];
   __shared__ T mat[D][PP * PP];
@@ -40,8 +41,17 @@ fdm_solve_kernel(const T* __restrict__ r, T* __restrict__ z,
     for (int q = lane; q < PP * PP; q += 64) mat[a][q] = Sa[q];
   }
   const int64_t base = e * N;
-  for (int q = lane; q < N; q += 64)
-    buf[0][q] = r[pel ? pel[base + q] : base + q];
+  T rsum = T(0);
+  for (int q = lane; q < N; q += 64) {
+    const T v = r[pel ? pel[base + q] : base + q];
+    buf[0][q] = v;
+    rsum += v;
+  }
+  if (elem_sum) {            // R_0 r of the coarse level, while r is here
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rsum += __shfl_down(rsum, off, 64);
+    if (lane == 0) elem_sum[e] = rsum;
+  }
   __syncthreads();
   int cur = 0;
 #pragma unroll
@@ -74,18 +84,46 @@ fdm_solve_kernel(const T* __restrict__ r, T* __restrict__ z,
       __syncthreads();
     }
   }
-  for (int q = lane; q < N; q += 64)
-    z[pel ? pel[base + q] : base + q] = buf[cur][q];
+  T wsum = T(0);
+  for (int q = lane; q < N; q += 64) {
+    const int64_t node = pel ? pel[base + q] : base + q;
+    const T v = buf[cur][q];
+    z[node] = v;
+    if (weighted_sum) wsum += weights[node] * v;
+  }
+  if (weighted_sum) {        // this element's share of weights . z
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wsum += __shfl_down(wsum, off, 64);
+    if (lane == 0) weighted_sum[e] = wsum;
+  }
+}
+
+// z[e][i] += yc[e] - shift[e / elems_per_member]  (element e owns the nodes
+// [e n, (e + 1) n)): the coarse correction and the mean projection of the
+// Schwarz preconditioner in one pass
+template <typename T>
+__global__ void __launch_bounds__(256)
+add_element_constants_kernel(T* __restrict__ z, const T* __restrict__ yc,
+                             const T* __restrict__ shift, int64_t total, int n,
+                             int64_t elems_per_member) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    const int64_t e = t / n;
+    z[t] += yc[e] - shift[e / elems_per_member];
+  }
 }
 
 template <typename T, int D>
 static int launch_fdm(int Pp, dim3 grid, hipStream_t st, const T* r, T* z,
                       const int64_t* pel, const T* S, const int32_t* cases,
-                      const T* w, int64_t E) {
+                      const T* w, int64_t E, const T* weights, T* elem_sum,
+                      T* weighted_sum) {
 #define SFEM_FDM_CASE(PPV)                                                    \
   case PPV:                                                                   \
     hipLaunchKernelGGL((fdm_solve_kernel<T, D, PPV>), grid, dim3(64), 0, st,  \
-                       r, z, pel, S, cases, w, E);                            \
+                       r, z, pel, S, cases, w, E, weights, elem_sum,          \
+                       weighted_sum);                                         \
     return SFEM_OK;
   switch (Pp) {
     SFEM_FDM_CASE(1) SFEM_FDM_CASE(2) SFEM_FDM_CASE(3) SFEM_FDM_CASE(4)
@@ -181,11 +219,71 @@ extern "C" int sfem_ell_chebyshev(const int32_t* cols, const void* vals,
   return SFEM_OK;
 }
 
+static int fdm_solve_impl(const void* r, void* z, const int64_t* pel,
+                          const void* S, const int32_t* cases,
+                          const void* inv_eigenvalues, const void* weights,
+                          void* elem_sum, void* weighted_sum,
+                          int64_t num_elements, int ndim, int Pp, int dtype,
+                          sfem_stream_t stream);
+
 extern "C" int sfem_fdm_solve(const void* r, void* z, const int64_t* pel,
                               const void* S, const int32_t* cases,
                               const void* inv_eigenvalues,
                               int64_t num_elements, int ndim, int Pp,
                               int dtype, sfem_stream_t stream) {
+  return fdm_solve_impl(r, z, pel, S, cases, inv_eigenvalues, nullptr, nullptr,
+                        nullptr, num_elements, ndim, Pp, dtype, stream);
+}
+
+extern "C" int sfem_fdm_solve_sums(const void* r, void* z, const int64_t* pel,
+                                   const void* S, const int32_t* cases,
+                                   const void* inv_eigenvalues,
+                                   const void* weights, void* elem_sum,
+                                   void* weighted_sum, int64_t num_elements,
+                                   int ndim, int Pp, int dtype,
+                                   sfem_stream_t stream) {
+  SFEM_REQUIRE(num_elements == 0 || (elem_sum && (!weighted_sum || weights)),
+               "sfem_fdm_solve_sums: elem_sum (and weights with "
+               "weighted_sum) required");
+  return fdm_solve_impl(r, z, pel, S, cases, inv_eigenvalues, weights,
+                        elem_sum, weighted_sum, num_elements, ndim, Pp, dtype,
+                        stream);
+}
+
+extern "C" int sfem_add_element_constants(void* z, const void* yc,
+                                          const void* shift,
+                                          int64_t num_elements, int n,
+                                          int64_t elems_per_member, int dtype,
+                                          sfem_stream_t stream) {
+  SFEM_REQUIRE(num_elements >= 0 && n >= 1 && elems_per_member >= 1,
+               "sfem_add_element_constants: bad sizes");
+  SFEM_REQUIRE(dtype == SFEM_F32 || dtype == SFEM_F64,
+               "sfem_add_element_constants: unknown dtype %d", dtype);
+  if (num_elements == 0) return SFEM_OK;
+  SFEM_REQUIRE(z && yc && shift, "sfem_add_element_constants: null pointer");
+  const int64_t total = num_elements * n;
+  int64_t blocks = (total + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == SFEM_F64)
+    hipLaunchKernelGGL(add_element_constants_kernel<double>,
+                       dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       (double*)z, (const double*)yc, (const double*)shift,
+                       total, n, elems_per_member);
+  else
+    hipLaunchKernelGGL(add_element_constants_kernel<float>,
+                       dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       (float*)z, (const float*)yc, (const float*)shift, total,
+                       n, elems_per_member);
+  SFEM_LAUNCH_CHECK();
+  return SFEM_OK;
+}
+
+static int fdm_solve_impl(const void* r, void* z, const int64_t* pel,
+                          const void* S, const int32_t* cases,
+                          const void* inv_eigenvalues, const void* weights,
+                          void* elem_sum, void* weighted_sum,
+                          int64_t num_elements, int ndim, int Pp, int dtype,
+                          sfem_stream_t stream) {
   SFEM_REQUIRE(num_elements >= 0 && ndim >= 1 && ndim <= 3 && Pp >= 1 &&
                    Pp <= FDM_MAX_P,
                "sfem_fdm_solve: ndim 1..3, 1 <= Pp <= %d", FDM_MAX_P);
@@ -198,7 +296,8 @@ extern "C" int sfem_fdm_solve(const void* r, void* z, const int64_t* pel,
   int rc;
 #define SFEM_FDM_DIM(T, DV)                                                   \
   launch_fdm<T, DV>(Pp, grid, st, (const T*)r, (T*)z, pel, (const T*)S,       \
-                    cases, (const T*)inv_eigenvalues, num_elements)
+                    cases, (const T*)inv_eigenvalues, num_elements,           \
+                    (const T*)weights, (T*)elem_sum, (T*)weighted_sum)
   if (dtype == SFEM_F64)
     rc = ndim == 3 ? SFEM_FDM_DIM(double, 3)
                    : (ndim == 2 ? SFEM_FDM_DIM(double, 2)

@@ -511,7 +511,41 @@ class SchwarzPressurePreconditioner:
     z[self.pel.reshape(-1)] = t.reshape(-1)
     return z
 
+  def _fused_setup(self):
+    """(weights per node, their element sums, total) for the one-pass closing
+    of `__call__`, or None where the pieces run separately (partitions, an
+    exchange on the pressure space, pressure nodes not numbered by element)."""
+    if not hasattr(self, '_fused'):
+      sem = self.sem
+      pmesh = sem.pressure.pspace.mesh
+      gi = pmesh.exchange_gather_indices
+      self._fused = None
+      from swirl_fem_amd import switches
+      if (self.pel_arg is None and self.Pp <= 10 and not self.partitioned and
+          (gi is None or gi.numel() == 0) and
+          switches.get('SFEM_PC_FUSED') != '0'):
+        b1, total = ns._pressure_mass_ones(sem, pmesh.dtype, pmesh.device)
+        full = b1.repeat(self.members).contiguous()
+        self._fused = (full, full.view(self.pel.shape).sum(dim=1),
+                       float(total))
+    return self._fused
+
   def __call__(self, r):
+    fused = self._fused_setup()
+    if fused is not None:
+      # the element sums of r and the elements' shares of the mean come out
+      # of the local solve; coarse correction and mean removal are one pass
+      from swirl_fem_amd import _ops
+      w, w_elem, total = fused
+      E, n = self.pel.shape
+      z, rc, share = _ops.fdm_solve_sums(r.contiguous(), None, self.S,
+                                         self.case32, self.inv_ev, w, self.d,
+                                         self.Pp)
+      yc = self._coarse_solve(rc)
+      B = self.members
+      shift = (share.view(B, -1).sum(dim=1) +
+               (yc * w_elem).view(B, -1).sum(dim=1)) / total
+      return _ops.add_element_constants_(z, yc, shift, n, E // B)
     z = self.local_solve(r)
     E, n = self.pel.shape
     if self.pel_arg is None:           # element e owns [e n, (e + 1) n)

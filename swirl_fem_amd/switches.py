@@ -110,6 +110,10 @@ SWITCHES = {
                          "'exchange' (the reference's M = QQ^T) or 'mass' "
                          '(inverse assembled lumped mass, scaled so that the '
                          "reference's stopping rule still holds)"),
+    'SFEM_PC_FUSED': ('1', 'navier_stokes/pressure_preconditioner.py',
+                      "0: the 'schwarz' preconditioner forms the element sums, "
+                      'the coarse correction and the mean removal in separate '
+                      'passes'),
     'SFEM_PC_COARSE_ITERS': (None, 'navier_stokes/pressure_preconditioner.py',
                              'Chebyshev steps of the coarse solve inside the '
                              "'schwarz' preconditioner (default: from the "

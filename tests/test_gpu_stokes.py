@@ -473,6 +473,16 @@ def test_schwarz_pressure_preconditioner():
   a, b = mean0(a), mean0(b)
   lhs, rhs = float(torch.dot(M(a), b)), float(torch.dot(a, M(b)))
   assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs))
+  # the one-pass closing (element sums and the mean's shares out of the local
+  # solve, `sfem_fdm_solve_sums` + `sfem_add_element_constants`) against the
+  # pieces run one after the other
+  assert M._fused_setup() is not None
+  fused = M(a)
+  saved, M._fused = M._fused, None
+  pieces = M(a)
+  M._fused = saved
+  assert float((fused - pieces).abs().max()) < 1e-12 * float(
+      pieces.abs().max())
   # Cartesian mesh: local_solve is the pseudo-inverse of E's diagonal blocks.
   # For r supported in ONE element with zero element mean, E_ee z = r there.
   r = torch.zeros(npr, dtype=p0.dtype, device=DEV)
